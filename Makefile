@@ -1,0 +1,22 @@
+# Builds the product library (HIP, gfx950 only) and the oracle (test infrastructure).
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+PKG     := zig-lz4_amd
+CSRC    := $(PKG)/csrc
+LIB     := $(PKG)/libzlz4_amd.so
+HIPSRC  := $(CSRC)/zlz4_capi.hip $(CSRC)/zlz4_frame.hip $(CSRC)/zlz4_decompress.hip \
+           $(CSRC)/zlz4_compress_fast.hip $(CSRC)/zlz4_compress_hc.hip
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+
+all: $(LIB) oracle
+
+$(LIB): $(HIPSRC) $(CSRC)/zlz4_device.hpp include/zlz4_amd.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

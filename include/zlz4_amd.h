@@ -1,0 +1,165 @@
+/*
+ * zlz4_amd.h -- C ABI of the MI355X-native LZ4 block codec (drop-in for the
+ * hot path of jedisct1/zig-lz4).  Every entry point below replaces one name
+ * that the reference re-exports from src/root.zig; the reference-side binding
+ * (Zig `extern "c"` declarations) is shown in INTEGRATION.md.
+ *
+ * All citations are relative to the reference tree (/root/reference/).
+ * Plain pointers and sizes only: no torch / HIP types in the signatures
+ * (a HIP stream is passed as `void*`, NULL = the default stream).
+ *
+ * Result convention (reference: Zig error unions, src/lz4.zig:48-55):
+ *   >= 0  number of bytes written
+ *   <  0  error, mirroring lz4.Error / lz4f.Error in declaration order.
+ * The library is HIP-only: there is NO CPU fallback.  If no gfx950 device is
+ * usable every compute entry point returns ZLZ4_ERR_DEVICE.
+ */
+#ifndef ZLZ4_AMD_H
+#define ZLZ4_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- lz4.Error (src/lz4.zig:48-55) ---- */
+#define ZLZ4_ERR_OUTPUT_TOO_SMALL      (-1)
+#define ZLZ4_ERR_INPUT_TOO_LARGE       (-2)
+#define ZLZ4_ERR_CORRUPTED_DATA        (-3)
+#define ZLZ4_ERR_DECOMPRESSION_FAILED  (-4)
+#define ZLZ4_ERR_INVALID_STATE         (-5)
+#define ZLZ4_ERR_ALLOCATION_FAILED     (-6)
+/* ---- new in this library ---- */
+#define ZLZ4_ERR_DEVICE                (-7)   /* HIP runtime / no gfx950 device / launch failure */
+#define ZLZ4_ERR_UNSUPPORTED           (-8)   /* level or acceleration not yet on the device path */
+
+/* ---- lz4f.Error (src/lz4f.zig:31-55): -(100 + 1-based declaration index) ---- */
+#define ZLZ4F_ERR_GENERIC                   (-101)
+#define ZLZ4F_ERR_MAX_BLOCK_SIZE_INVALID    (-102)
+#define ZLZ4F_ERR_BLOCK_MODE_INVALID        (-103)
+#define ZLZ4F_ERR_PARAMETER_INVALID         (-104)
+#define ZLZ4F_ERR_COMPRESSION_LEVEL_INVALID (-105)
+#define ZLZ4F_ERR_HEADER_VERSION_WRONG      (-106)
+#define ZLZ4F_ERR_BLOCK_CHECKSUM_INVALID    (-107)
+#define ZLZ4F_ERR_RESERVED_FLAG_SET         (-108)
+#define ZLZ4F_ERR_ALLOCATION_FAILED         (-109)
+#define ZLZ4F_ERR_SRC_SIZE_TOO_LARGE        (-110)
+#define ZLZ4F_ERR_DST_MAX_SIZE_TOO_SMALL    (-111)
+#define ZLZ4F_ERR_FRAME_HEADER_INCOMPLETE   (-112)
+#define ZLZ4F_ERR_FRAME_TYPE_UNKNOWN        (-113)
+#define ZLZ4F_ERR_FRAME_SIZE_WRONG          (-114)
+#define ZLZ4F_ERR_SRC_PTR_WRONG             (-115)
+#define ZLZ4F_ERR_DECOMPRESSION_FAILED      (-116)
+#define ZLZ4F_ERR_HEADER_CHECKSUM_INVALID   (-117)
+#define ZLZ4F_ERR_CONTENT_CHECKSUM_INVALID  (-118)
+
+/* ---- constants re-exported by src/root.zig:46-49 / src/lz4.zig:12-25 / src/lz4hc.zig:28-31 ---- */
+#define ZLZ4_MINMATCH            4
+#define ZLZ4_MAX_INPUT_SIZE      0x7E000000u
+#define ZLZ4_DISTANCE_MAX        65535u
+#define ZLZ4HC_CLEVEL_MIN        2
+#define ZLZ4HC_CLEVEL_DEFAULT    9
+#define ZLZ4HC_CLEVEL_MAX        12
+#define ZLZ4F_MAGICNUMBER        0x184D2204u     /* src/lz4f.zig:12 */
+
+/* ======================================================================
+ * 1. Single-buffer entry points, HOST pointers -- the names root.zig binds.
+ *    Each stages the buffer to the current HIP device, runs the batch kernel
+ *    on one block and copies the result back (PCIe-inclusive; use section 2
+ *    for throughput).  Re-entrant like the reference (no global state besides
+ *    the lazily created device context).
+ * ====================================================================== */
+
+/* replaces lz4.compressBound, src/lz4.zig:80-83 (pure arithmetic, no device) */
+size_t  zlz4_compress_bound(size_t input_size);
+
+/* replaces lz4.compressDefault, src/lz4.zig:283-285 */
+int64_t zlz4_compress_default(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap);
+
+/* replaces lz4.compressFast, src/lz4.zig:292-447 (acceleration clamped to [1,65537] as :321) */
+int64_t zlz4_compress_fast(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                           uint32_t acceleration);
+
+/* replaces lz4hc.compressHC, src/lz4hc.zig:1440-1453.  Levels <2 -> 9, >12 -> 12 (:1445).
+ * Levels 3..9 (hash chain) run on the device; 2 and 10..12 return ZLZ4_ERR_UNSUPPORTED. */
+int64_t zlz4_compress_hc(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                         int32_t compression_level);
+
+/* replaces lz4.decompressSafe, src/lz4.zig:257-259 (decompressGeneric :89-251, no dict) */
+int64_t zlz4_decompress_safe(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap);
+
+/* ======================================================================
+ * 2. Batch entry points, DEVICE pointers -- the data-parallel hot path.
+ *    Block i reads  d_in  + d_in_off[i]  (d_in_len[i] bytes) and writes
+ *    d_out + d_out_off[i] (capacity d_out_cap[i]); d_result[i] receives what
+ *    the single-buffer call would have returned for that block.  All arrays
+ *    live in device memory.  Kernels are enqueued on `stream` (hipStream_t)
+ *    and the call returns without synchronising.  Return: 0 or ZLZ4_ERR_*.
+ * ====================================================================== */
+int32_t zlz4_batch_compress_fast(void *stream,
+                                 const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                 uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                                 int64_t *d_result, uint32_t nblocks, uint32_t max_in_len,
+                                 uint32_t acceleration);
+
+int32_t zlz4_batch_decompress_safe(void *stream,
+                                   const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                   uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                                   int64_t *d_result, uint32_t nblocks);
+
+/* workspace for the HC path: bytes needed for `nblocks` blocks of at most `max_in_len` bytes */
+size_t  zlz4_batch_compress_hc_workspace(uint32_t nblocks, uint32_t max_in_len);
+int32_t zlz4_batch_compress_hc(void *stream,
+                               const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                               uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                               int64_t *d_result, uint32_t nblocks, uint32_t max_in_len,
+                               int32_t compression_level, void *d_workspace, size_t workspace_bytes);
+
+/* ======================================================================
+ * 3. Frame container (src/lz4f.zig), HOST pointers.
+ * ====================================================================== */
+/* src/lz4f.zig:106-122 (FrameInfo + Preferences flattened; NULL = defaults) */
+typedef struct zlz4f_prefs {
+    uint32_t block_size_id;     /* 0 default, 4 = 64 KiB, 5 = 256 KiB, 6 = 1 MiB, 7 = 4 MiB  (:64-79) */
+    uint32_t block_mode;        /* 0 linked, 1 independent (header bit only, :159-161)         */
+    uint32_t content_checksum;  /* 0 / 1                                                      */
+    uint32_t block_checksum;    /* 0 / 1                                                      */
+    uint64_t content_size;      /* 0 = unknown                                                */
+    uint32_t dict_id;           /* 0 = none                                                   */
+    int32_t  compression_level; /* <= 0 fast (accel 1); > 0 -> compressHC(level)  (:393-404)   */
+} zlz4f_prefs;
+
+/* replaces lz4f.compressFrameBound, src/lz4f.zig:274-301 (pure arithmetic) */
+size_t  zlz4f_compress_frame_bound(size_t src_size, const zlz4f_prefs *prefs);
+/* replaces lz4f.compressFrame, src/lz4f.zig:354-446 (the unused allocator argument is dropped) */
+int64_t zlz4f_compress_frame(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                             const zlz4f_prefs *prefs);
+/* replaces lz4f.decompressFrame, src/lz4f.zig:541-638 */
+int64_t zlz4f_decompress_frame(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap);
+/* replaces lz4f.headerSize, src/lz4f.zig:451-480 (pure arithmetic) */
+int64_t zlz4f_header_size(const uint8_t *src, size_t src_len);
+
+/* Device-resident frame variants (config 5: per-GPU shard already in HBM).
+ * src/dst are DEVICE pointers; the frame header/end-mark bytes and the size
+ * prefix sum are produced on the device too.  Synchronises `stream` before
+ * returning the frame size. */
+int64_t zlz4f_compress_frame_device(void *stream, const uint8_t *d_src, size_t src_len,
+                                    uint8_t *d_dst, size_t dst_cap, const zlz4f_prefs *prefs);
+int64_t zlz4f_decompress_frame_device(void *stream, const uint8_t *d_src, size_t src_len,
+                                      uint8_t *d_dst, size_t dst_cap);
+
+/* ======================================================================
+ * 4. Introspection
+ * ====================================================================== */
+/* 0 if a gfx950 device is usable by this process, else ZLZ4_ERR_DEVICE */
+int32_t     zlz4_device_check(void);
+const char *zlz4_version_string(void);
+/* human-readable name of a ZLZ4_ERR_* / ZLZ4F_ERR_* code (mirrors the Zig error names) */
+const char *zlz4_error_name(int64_t code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZLZ4_AMD_H */

@@ -1,0 +1,145 @@
+"""HIP path vs the oracle, bit-exact, through the C ABI (run on the GPU box: pytest -m gpu)."""
+import numpy as np
+import pytest
+
+import cases
+import datagen as dg
+import gpu_harness as gh
+
+pytestmark = pytest.mark.gpu
+
+ALL_INPUTS = cases.reference_test_inputs() + list(cases.kat_inputs().items()) + cases.seeded_cases(heavy=True)
+
+
+def _cmp(names, got, want):
+    bad = []
+    for name, (n, data), w in zip(names, got, want):
+        if isinstance(w, int):
+            if n != w:
+                bad.append("%s: status %d, oracle %d" % (name, n, w))
+        elif n != len(w) or data != w:
+            first = next((i for i, (a, b) in enumerate(zip(data, w)) if a != b), min(len(data), len(w)))
+            bad.append("%s: size %d vs oracle %d, first diff at %d" % (name, n, len(w), first))
+    assert not bad, "%d/%d mismatches: %s" % (len(bad), len(names), "; ".join(bad[:8]))
+
+
+def test_compress_default_bit_exact(zl, oracle, gpu):
+    names = [n for n, _ in ALL_INPUTS]
+    items = [b for _, b in ALL_INPUTS]
+    got = gh.compress_fast(zl, items, gpu)
+    want = [oracle.compress_default(b) for b in items]
+    _cmp(names, got, want)
+
+
+@pytest.mark.parametrize("accel", [2, 7, 63, 64, 65, 1000, 65537, 0])
+def test_compress_fast_acceleration_bit_exact(zl, oracle, gpu, accel):
+    sel = [(n, b) for n, b in ALL_INPUTS if len(b) <= 70000]
+    got = gh.compress_fast(zl, [b for _, b in sel], gpu, accel=accel)
+    want = [oracle.compress_fast(b, accel) for _, b in sel]
+    _cmp([n for n, _ in sel], got, want)
+
+
+def test_decompress_safe_bit_exact(zl, oracle, gpu):
+    names, comp, caps, want = [], [], [], []
+    for n, b in ALL_INPUTS:
+        for lvl in (0, 9):
+            c = oracle.compress_default(b) if lvl == 0 else oracle.compress_hc(b, 9)
+            names.append("%s/l%d" % (n, lvl))
+            comp.append(c)
+            caps.append(len(b))
+            want.append(oracle.decompress_safe(c, len(b)))
+            assert want[-1] == b
+    got = gh.decompress(zl, comp, caps, gpu)
+    _cmp(names, got, want)
+
+
+def test_decompress_capacity_larger_and_smaller(zl, oracle, gpu):
+    names, comp, caps, want = [], [], [], []
+    for n, b in ALL_INPUTS[:40] + cases.seeded_cases()[-30:]:
+        c = oracle.compress_default(b)
+        for cap in (len(b) + 100, max(0, len(b) - 1), len(b) // 2, 0, 1):
+            names.append("%s/cap%d" % (n, cap))
+            comp.append(c)
+            caps.append(cap)
+            want.append(oracle.decompress_safe(c, cap))
+    got = gh.decompress(zl, comp, caps, gpu)
+    # on error only the status is specified; on success bytes must match
+    _cmp(names, got, want)
+
+
+def test_decompress_malformed_status_parity(zl, oracle, gpu):
+    """Truncations, bit flips and hand-made bad streams: same status class as the reference algorithm."""
+    base = [oracle.compress_default(b) for _, b in ALL_INPUTS if 20 <= len(b) <= 5000][:30]
+    rng = np.random.default_rng(1234)
+    names, comp, caps = [], [], []
+    for i, c in enumerate(base):
+        for cut in (1, 2, 3, len(c) // 2, len(c) - 1):
+            names.append("trunc%d/%d" % (i, cut)); comp.append(c[:cut]); caps.append(8192)
+        for k in range(6):
+            m = bytearray(c)
+            pos = int(rng.integers(0, len(m)))
+            m[pos] ^= 1 << int(rng.integers(0, 8))
+            names.append("flip%d/%d" % (i, k)); comp.append(bytes(m)); caps.append(8192)
+    hand = [b"\x00", b"\x10", b"\x10A", b"\x1fA\x00\x00", b"\x00\x00\x00", b"\x10A\x01", b"\x10A\x02\x00",
+            b"\xf0", b"\xf0\xff", b"\xf0\xff\xff\x00", b"\x0f\x01\x00", b"\x1fA\x01\x00\xff", b"\x40ABCD\x04\x00",
+            b"\x4fABCD\x04\x00\xff\xff\x00", b"\x40ABCD\x05\x00", b"\x00\x01\x00", b"\x11A\x01\x00\x10"]
+    for i, h in enumerate(hand):
+        for cap in (0, 3, 4, 64, 100000):
+            names.append("hand%d/cap%d" % (i, cap)); comp.append(h); caps.append(cap)
+    want = []
+    for c, cap in zip(comp, caps):
+        w = oracle.decompress_safe(c, cap)
+        want.append(w)
+    got = gh.decompress(zl, comp, caps, gpu)
+    _cmp(names, got, want)
+
+
+@pytest.mark.parametrize("level", [9, 3, 4, 5, 6, 7, 8])
+def test_compress_hc_bit_exact(zl, oracle, gpu, level):
+    sel = ALL_INPUTS if level == 9 else [(n, b) for n, b in ALL_INPUTS if len(b) <= 70000]
+    got = gh.compress_hc(zl, [b for _, b in sel], gpu, level)
+    want = [oracle.compress_hc(b, level) for _, b in sel]
+    _cmp([n for n, _ in sel], got, want)
+
+
+def test_compress_output_too_small_parity(zl, oracle, gpu):
+    """Destination smaller than the bound: identical OutputTooSmall / success decision (Appendix A Q10, H7)."""
+    names, items, caps = [], [], []
+    for n, b in ALL_INPUTS:
+        if not (13 <= len(b) <= 20000):
+            continue
+        full = len(oracle.compress_default(b))
+        for cap in (full, full - 1, full + 1, full // 2, 1, 0, 2, 3):
+            names.append("%s/cap%d" % (n, cap)); items.append(b); caps.append(max(0, cap))
+    got = gh.compress_fast(zl, items, gpu, caps=caps)
+    want = [oracle.compress_default(b, cap=c) for b, c in zip(items, caps)]
+    _cmp(names, got, want)
+
+
+def test_batch_of_64k_blocks_all_distributions(zl, oracle, gpu):
+    """configs[1]-shaped batch (64 KiB blocks) at a size the oracle finishes in seconds."""
+    for dist in dg.GENERATORS:
+        blocks = dg.make_blocks(dist, 96, 65536, seed=21)
+        items = [bytes(b) for b in blocks]
+        got = gh.compress_fast(zl, items, gpu)
+        want = [oracle.compress_default(b) for b in items]
+        _cmp(["%s#%d" % (dist, i) for i in range(len(items))], got, want)
+        dec = gh.decompress(zl, want, [65536] * len(items), gpu)
+        _cmp(["%s#%d" % (dist, i) for i in range(len(items))], dec, items)
+
+
+def test_single_buffer_entry_points(zl, oracle, gpu):
+    """The root.zig-shaped host-pointer calls (stage -> kernel -> copy back)."""
+    for name, b in cases.reference_test_inputs()[:12]:
+        c = zl.compressDefault(b)
+        assert c == oracle.compress_default(b), name
+        assert zl.decompressSafe(c, len(b)) == b, name
+        h = zl.compressHC(b, 9)
+        assert h == oracle.compress_hc(b, 9), name
+        assert zl.decompressSafe(h, len(b) + 7) == b, name
+    with pytest.raises(zl.Lz4Error) as e:
+        zl.decompressSafe(b"\x1fA\x00\x00", 100)
+    assert e.value.name == "CorruptedData"
+    with pytest.raises(zl.Lz4Error) as e:
+        zl.compressDefault(b"A" * 100, dst_cap=3)
+    assert e.value.name == "OutputTooSmall"

@@ -1,0 +1,225 @@
+// zlz4_capi.hip -- the C ABI declared in include/zlz4_amd.h.
+//
+// Host side of the MI355X LZ4 codec: validates arguments the way the reference
+// entry points do (src/lz4.zig, src/lz4hc.zig, src/lz4f.zig -- cited per function),
+// stages host buffers, and enqueues the gfx950 kernels.  There is no CPU codec in
+// here: without a usable HIP device every compute call returns ZLZ4_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/zlz4_amd.h"
+
+// kernel launchers (one per .hip file)
+extern "C" int zlz4_launch_decompress_safe(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
+                                           const uint64_t *, const uint32_t *, int64_t *, uint32_t);
+extern "C" int zlz4_launch_compress_fast(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
+                                         const uint64_t *, const uint32_t *, int64_t *, uint32_t, uint32_t, uint32_t);
+extern "C" int zlz4_launch_compress_hc(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
+                                       const uint64_t *, const uint32_t *, int64_t *, uint32_t, uint32_t, int32_t,
+                                       void *, size_t);
+extern "C" size_t zlz4_hc_workspace_bytes(uint32_t nblocks, uint32_t max_in_len);
+extern "C" int zlz4_launch_frame_helpers_init(void);
+
+namespace {
+
+// ---------------------------------------------------------------- device context
+std::once_flag g_once;
+int g_device_ok = ZLZ4_ERR_DEVICE;
+
+void probe_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) return;   // kernels are built for gfx950 only
+    g_device_ok = 0;
+}
+
+bool device_ok() {
+    std::call_once(g_once, probe_device);
+    return g_device_ok == 0;
+}
+
+// RAII device allocation
+struct DevBuf {
+    void *p = nullptr;
+    explicit DevBuf(size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) p = nullptr; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct BlockDesc { uint64_t in_off; uint32_t in_len; uint64_t out_off; uint32_t out_cap; };
+
+enum class Op { Fast, Hc, Decompress };
+
+// One block, host pointers: stage -> kernel -> copy back.
+int64_t run_single(Op op, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, uint32_t accel,
+                   int32_t level) {
+    if (!device_ok()) return ZLZ4_ERR_DEVICE;
+    if (src_len > 0xFFFFFFFFull) return op == Op::Decompress ? ZLZ4_ERR_CORRUPTED_DATA : ZLZ4_ERR_INPUT_TOO_LARGE;
+    // the kernels index with 32 bits; a destination larger than 4 GiB-1 is clamped (never reached:
+    // compressBound(0x7E000000) and the largest decodable block both fit)
+    const uint32_t cap32 = dst_cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dst_cap;
+    const uint32_t len32 = (uint32_t)src_len;
+
+    DevBuf d_in(src_len), d_out(cap32), d_meta(64);
+    if (!d_in.p || !d_out.p || !d_meta.p) return ZLZ4_ERR_ALLOCATION_FAILED;
+    struct Meta { uint64_t in_off; uint64_t out_off; int64_t result; uint32_t in_len; uint32_t out_cap; } m;
+    m.in_off = 0; m.out_off = 0; m.result = 0; m.in_len = len32; m.out_cap = cap32;
+    hipStream_t st = nullptr;
+    if (src_len && hipMemcpyAsync(d_in.p, src, src_len, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    if (hipMemcpyAsync(d_meta.p, &m, sizeof m, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    auto *dm = d_meta.as<uint8_t>();
+    const uint64_t *p_in_off = reinterpret_cast<const uint64_t *>(dm + offsetof(Meta, in_off));
+    const uint64_t *p_out_off = reinterpret_cast<const uint64_t *>(dm + offsetof(Meta, out_off));
+    int64_t *p_res = reinterpret_cast<int64_t *>(dm + offsetof(Meta, result));
+    const uint32_t *p_in_len = reinterpret_cast<const uint32_t *>(dm + offsetof(Meta, in_len));
+    const uint32_t *p_out_cap = reinterpret_cast<const uint32_t *>(dm + offsetof(Meta, out_cap));
+    int rc;
+    if (op == Op::Fast) {
+        rc = zlz4_launch_compress_fast(st, d_in.as<uint8_t>(), p_in_off, p_in_len, d_out.as<uint8_t>(), p_out_off,
+                                       p_out_cap, p_res, 1, len32, accel);
+    } else if (op == Op::Hc) {
+        const size_t ws = zlz4_hc_workspace_bytes(1, len32);
+        DevBuf d_ws(ws);
+        if (!d_ws.p) return ZLZ4_ERR_ALLOCATION_FAILED;
+        rc = zlz4_launch_compress_hc(st, d_in.as<uint8_t>(), p_in_off, p_in_len, d_out.as<uint8_t>(), p_out_off,
+                                     p_out_cap, p_res, 1, len32, level, d_ws.p, ws);
+        if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = ZLZ4_ERR_DEVICE;   // d_ws dies at scope end
+    } else {
+        rc = zlz4_launch_decompress_safe(st, d_in.as<uint8_t>(), p_in_off, p_in_len, d_out.as<uint8_t>(), p_out_off,
+                                         p_out_cap, p_res, 1);
+    }
+    if (rc != 0) return rc;
+    int64_t result = 0;
+    if (hipMemcpyAsync(&result, p_res, sizeof result, hipMemcpyDeviceToHost, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    if (hipStreamSynchronize(st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    if (result > 0) {
+        if ((uint64_t)result > dst_cap) return ZLZ4_ERR_DEVICE;   // cannot happen; never overrun the caller
+        if (hipMemcpy(dst, d_out.p, (size_t)result, hipMemcpyDeviceToHost) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    }
+    return result;
+}
+
+// src/lz4hc.zig:1445 + :1464-1466 level normalisation, strategy table :72-86
+int32_t normalise_hc_level(int32_t level) {
+    if (level < ZLZ4HC_CLEVEL_MIN) level = ZLZ4HC_CLEVEL_DEFAULT;
+    if (level > ZLZ4HC_CLEVEL_MAX) level = ZLZ4HC_CLEVEL_MAX;
+    return level;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- introspection
+int32_t zlz4_device_check(void) { return device_ok() ? 0 : ZLZ4_ERR_DEVICE; }
+
+const char *zlz4_version_string(void) { return "zlz4-amd 0.1.0 (gfx950)"; }
+
+const char *zlz4_error_name(int64_t code) {
+    switch (code) {
+        case ZLZ4_ERR_OUTPUT_TOO_SMALL: return "OutputTooSmall";
+        case ZLZ4_ERR_INPUT_TOO_LARGE: return "InputTooLarge";
+        case ZLZ4_ERR_CORRUPTED_DATA: return "CorruptedData";
+        case ZLZ4_ERR_DECOMPRESSION_FAILED: return "DecompressionFailed";
+        case ZLZ4_ERR_INVALID_STATE: return "InvalidState";
+        case ZLZ4_ERR_ALLOCATION_FAILED: return "AllocationFailed";
+        case ZLZ4_ERR_DEVICE: return "DeviceError";
+        case ZLZ4_ERR_UNSUPPORTED: return "Unsupported";
+        case ZLZ4F_ERR_GENERIC: return "Generic";
+        case ZLZ4F_ERR_MAX_BLOCK_SIZE_INVALID: return "MaxBlockSizeInvalid";
+        case ZLZ4F_ERR_BLOCK_MODE_INVALID: return "BlockModeInvalid";
+        case ZLZ4F_ERR_PARAMETER_INVALID: return "ParameterInvalid";
+        case ZLZ4F_ERR_COMPRESSION_LEVEL_INVALID: return "CompressionLevelInvalid";
+        case ZLZ4F_ERR_HEADER_VERSION_WRONG: return "HeaderVersionWrong";
+        case ZLZ4F_ERR_BLOCK_CHECKSUM_INVALID: return "BlockChecksumInvalid";
+        case ZLZ4F_ERR_RESERVED_FLAG_SET: return "ReservedFlagSet";
+        case ZLZ4F_ERR_ALLOCATION_FAILED: return "AllocationFailed";
+        case ZLZ4F_ERR_SRC_SIZE_TOO_LARGE: return "SrcSizeTooLarge";
+        case ZLZ4F_ERR_DST_MAX_SIZE_TOO_SMALL: return "DstMaxSizeTooSmall";
+        case ZLZ4F_ERR_FRAME_HEADER_INCOMPLETE: return "FrameHeaderIncomplete";
+        case ZLZ4F_ERR_FRAME_TYPE_UNKNOWN: return "FrameTypeUnknown";
+        case ZLZ4F_ERR_FRAME_SIZE_WRONG: return "FrameSizeWrong";
+        case ZLZ4F_ERR_SRC_PTR_WRONG: return "SrcPtrWrong";
+        case ZLZ4F_ERR_DECOMPRESSION_FAILED: return "DecompressionFailed";
+        case ZLZ4F_ERR_HEADER_CHECKSUM_INVALID: return "HeaderChecksumInvalid";
+        case ZLZ4F_ERR_CONTENT_CHECKSUM_INVALID: return "ContentChecksumInvalid";
+        default: return code >= 0 ? "ok" : "unknown";
+    }
+}
+
+// ---------------------------------------------------------------- single buffer, host pointers
+size_t zlz4_compress_bound(size_t n) {                      // src/lz4.zig:80-83
+    if (n > ZLZ4_MAX_INPUT_SIZE) return 0;
+    return n + (n / 255) + 16;
+}
+
+int64_t zlz4_compress_fast(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, uint32_t accel) {
+    if (n > ZLZ4_MAX_INPUT_SIZE) return ZLZ4_ERR_INPUT_TOO_LARGE;   // src/lz4.zig:296
+    if (n == 0) return 0;                                           // :299
+    return run_single(Op::Fast, src, n, dst, cap, accel, 0);
+}
+
+int64_t zlz4_compress_default(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {   // src/lz4.zig:283-285
+    return zlz4_compress_fast(src, n, dst, cap, 1);
+}
+
+int64_t zlz4_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int32_t level) {
+    if (n > ZLZ4_MAX_INPUT_SIZE) return ZLZ4_ERR_INPUT_TOO_LARGE;   // src/lz4hc.zig:1442
+    if (n == 0) return 0;                                           // :1443
+    if (cap == 0) return ZLZ4_ERR_OUTPUT_TOO_SMALL;                 // :1461
+    level = normalise_hc_level(level);
+    if (level < 3 || level > 9) return ZLZ4_ERR_UNSUPPORTED;        // lz4mid / lz4opt strategies: not on device yet
+    return run_single(Op::Hc, src, n, dst, cap, 0, level);
+}
+
+int64_t zlz4_decompress_safe(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (n == 0) return 0;                                           // src/lz4.zig:97
+    if (cap == 0) return 0;                                         // :98
+    return run_single(Op::Decompress, src, n, dst, cap, 0, 0);
+}
+
+// ---------------------------------------------------------------- batch, device pointers
+int32_t zlz4_batch_compress_fast(void *stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                 uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                                 int64_t *d_result, uint32_t nblocks, uint32_t max_in_len, uint32_t acceleration) {
+    if (!device_ok()) return ZLZ4_ERR_DEVICE;
+    return zlz4_launch_compress_fast((hipStream_t)stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                     d_result, nblocks, max_in_len, acceleration);
+}
+
+int32_t zlz4_batch_decompress_safe(void *stream, const uint8_t *d_in, const uint64_t *d_in_off,
+                                   const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                   const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks) {
+    if (!device_ok()) return ZLZ4_ERR_DEVICE;
+    return zlz4_launch_decompress_safe((hipStream_t)stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                       d_result, nblocks);
+}
+
+size_t zlz4_batch_compress_hc_workspace(uint32_t nblocks, uint32_t max_in_len) {
+    return zlz4_hc_workspace_bytes(nblocks, max_in_len);
+}
+
+int32_t zlz4_batch_compress_hc(void *stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                               uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                               int64_t *d_result, uint32_t nblocks, uint32_t max_in_len, int32_t level,
+                               void *d_workspace, size_t workspace_bytes) {
+    if (!device_ok()) return ZLZ4_ERR_DEVICE;
+    level = normalise_hc_level(level);
+    if (level < 3 || level > 9) return ZLZ4_ERR_UNSUPPORTED;
+    if (workspace_bytes < zlz4_hc_workspace_bytes(nblocks, max_in_len) || (!d_workspace && nblocks))
+        return ZLZ4_ERR_INVALID_STATE;
+    return zlz4_launch_compress_hc((hipStream_t)stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                   d_result, nblocks, max_in_len, level, d_workspace, workspace_bytes);
+}
+
+}  // extern "C"

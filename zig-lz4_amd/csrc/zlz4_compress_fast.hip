@@ -1,0 +1,283 @@
+// zlz4_compress_fast.hip -- LZ4 "fast" block compressor for gfx950, one wavefront per block.
+//
+// Replaces lz4.compressFast / lz4.compressDefault (reference src/lz4.zig:283-447,
+// helpers :449-519).  Output is byte-identical to the Zig algorithm, including
+// the quirks listed in SURVEY.md Appendix A.1:
+//   Q1 position 0 is never inserted / never matchable (0 == empty)   :317, :345
+//   Q2 the skip schedule  step = searchMatchNb >> 6  with searchMatchNb starting at
+//      `acceleration`, and the bail-out test on the post-increment forwardIp      :322-338
+//   Q3 probe = read table, 4 validity tests, unconditional put                     :342-350
+//   Q4 no backward extension, Q5 forward extension up to srcSize-5               :401-413
+//   Q6 after a match only the byte right after it is inserted                    :435-442
+//
+// How the serial probe loop becomes 64-wide without changing a byte
+// -----------------------------------------------------------------
+// A search that starts at F0 visits a position sequence that depends only on F0 and
+// the acceleration a (not on data): with c = max(64, a) and S(x) = sum_{y<x} (y >> 6)
+//     U(0) = F0                        bail iff F0 + a > L
+//     U(1) = F0 + a                    bail iff U(1) + (a >> 6) > L
+//     U(u) = F0 + a + S(c+u-1) - S(c)  bail iff U(u) + ((c+u-1) >> 6) > L      (u >= 2)
+// (L = srcSize - 12).  The iterations in which the reference's step is 0 re-probe the
+// same position, see match == ip, fail `match < ip` and re-put the same value: they
+// change nothing and are skipped.  Lane i of a batch takes probe u = ub + i.  What a
+// probe reads from the hash table is either the value from before the batch or the
+// position of the nearest earlier lane of the batch with the same hash; those lanes
+// are found with one LDS write/read-back (losers of the write race are members of a
+// duplicate-hash group) plus one ballot per duplicate group.  The first valid lane
+// wins (ballot + ffs); lanes after it put their old table value back, so the table
+// ends up exactly as the serial loop would have left it.
+#include "zlz4_device.hpp"
+
+namespace zlz4 {
+
+__device__ __forceinline__ uint32_t hash4(uint32_t seq) { return (seq * kHashMul) >> 20; }   // src/lz4.zig:75-77
+
+// S(x) = sum_{y < x} (y >> 6)
+__device__ __forceinline__ uint32_t skip_sum(uint32_t x) {
+    const uint32_t q = x >> 6, r = x & 63u;
+    return 32u * q * (q - 1u) + q * r;      // q == 0 -> 0 (32*0*(-1) wraps to 0)
+}
+
+// literal-only sequence: compressAsLiterals (:449-482) and finishCompression (:484-519)
+__device__ __forceinline__ int64_t emit_last_literals(uint8_t *dst, uint32_t dst_len, uint32_t op,
+                                                       const uint8_t *lit_src, uint32_t lit, uint32_t lane) {
+    if (lit == 0) return (int64_t)op;                                   // :488
+    const uint32_t nle = ext_len_bytes(lit);
+    if ((uint64_t)op + 1u + nle + lit > dst_len) return kErrOutputTooSmall;   // :491-514 / :454-477
+    if (lane == 0) dst[op] = (uint8_t)((lit >= 15u ? 15u : lit) << 4);
+    if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
+    copy_bytes(dst + op + 1u + nle, lit_src, lit, lane);
+    return (int64_t)(op + 1u + nle + lit);
+}
+
+template <typename T>   // T = uint16_t when every stored position fits 16 bits, else uint32_t
+__global__ __launch_bounds__(256) void k_compress_fast(
+    const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
+    const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
+    const uint64_t *__restrict__ d_out_off, const uint32_t *__restrict__ d_out_cap,
+    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    const uint32_t blk = rfl(blockIdx.x * (blockDim.x >> 6) + wave_in_wg);
+    if (blk >= nblocks) return;
+    // HashTable, src/lz4.zig:263-277.  volatile: lanes communicate through it (write / read-back race
+    // detection), so the compiler must neither forward stores to loads nor drop the re-reads.
+    volatile T *table = reinterpret_cast<volatile T *>(lds_raw) + wave_in_wg * 4096u;
+
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t src_size = rfl(d_in_len[blk]);
+    const uint32_t dst_len = rfl(d_out_cap[blk]);
+
+    int64_t res;
+    if (src_size > kMaxInput) {                                         // :296
+        res = kErrInputTooLarge;
+    } else if (src_size == 0) {                                         // :299
+        res = 0;
+    } else if (src_size < kMfLimit + 1u) {                              // :302-304
+        res = emit_last_literals(dst, dst_len, 0, src, src_size, lane);
+    } else {
+        // HashTable.init(): zero fill (:266-268)
+        {
+            u32x4 z = {0, 0, 0, 0};
+            u32x4 *t4 = reinterpret_cast<u32x4 *>(lds_raw) + wave_in_wg * (4096u * sizeof(T) / 16u);
+            const uint32_t n16 = 4096u * sizeof(T) / 16u;
+            for (uint32_t k = lane; k < n16; k += 64u) t4[k] = z;
+        }
+        const uint32_t accel = acceleration < 1u ? 1u : (acceleration > 65537u ? 65537u : acceleration);   // :321
+        const uint32_t cbase = accel > 64u ? accel : 64u;
+        const uint32_t s_cbase = skip_sum(cbase);
+        const uint32_t L = src_size - kMfLimit;                         // mflimitPlusOne :313
+        const uint32_t match_limit = src_size - kLastLiterals;          // :314
+        const uint64_t lane_bit = 1ull << lane;
+        const uint64_t lanes_below = lane_bit - 1ull;
+
+        uint32_t anchor = 0, op = 0;
+        uint32_t F0 = 1;                                                // :317
+        bool has_ins = false;    // pending put(anchor) of :438-441, folded into the next batch as lane 0
+        bool failed = false;
+
+        while (F0 < L) {                                                // :320
+            // ---------------- search: 64 probes per step ----------------
+            int32_t ub = -1;      // probe index of lane 0 (-1 = the pending insert pseudo-probe)
+            bool found = false, bailed = false;
+            uint32_t m_pos = 0, m_cand = 0, m_local = 0;
+            bool m_local_done = false;
+            for (;;) {
+                const int32_t u = ub + (int32_t)lane;
+                uint32_t pos, step_next;
+                if (u <= 0) {
+                    pos = (u < 0) ? F0 - 1u : F0;
+                    step_next = accel;                  // u == 0: bail iff F0 + a > L  (:331-335, first iteration)
+                } else if (u == 1) {
+                    pos = F0 + accel;
+                    step_next = accel >> 6;
+                } else {
+                    const uint32_t x = cbase + (uint32_t)u - 1u;
+                    pos = F0 + accel + skip_sum(x) - s_cbase;
+                    step_next = x >> 6;
+                }
+                const bool is_probe = u >= 0;
+                const bool bail = is_probe && ((uint64_t)pos + step_next > L);
+                const uint64_t bail_mask = ballot(bail);
+                // bail is monotone in u: everything from the first bailing lane on is out of the search
+                const uint32_t nb = bail_mask ? first_lane(bail_mask) : 64u;
+                const bool active = (lane < nb) && (is_probe || has_ins);
+
+                // forward data: 16 B when they are inside the block, else the 4 hashed bytes only
+                const bool have16 = active && (pos + 16u <= src_size);
+                u32x4 fwd = {0, 0, 0, 0};
+                if (have16) fwd = ld128(src + pos);
+                else if (active) fwd.x = ld32(src + pos);
+                const uint32_t h = hash4(fwd.x);                        // :341
+
+                // table read / speculative put / read-back
+                uint32_t old = 0, rb = 0;
+                if (active) {
+                    old = table[h];                                     // :342
+                    table[h] = (T)pos;                                  // :350 (speculative)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (active) rb = table[h];
+                // duplicate-hash groups inside the batch
+                uint64_t losers = ballot(active && rb != (uint32_t)(T)pos);
+                uint64_t grp = lane_bit;
+                int32_t pred = -1;
+                while (losers) {
+                    const uint32_t l = first_lane(losers);
+                    const uint32_t hh = rdlane(h, l);
+                    const uint64_t same = ballot(active && h == hh);
+                    if (active && h == hh) {
+                        grp = same;
+                        const uint64_t below = same & lanes_below;
+                        pred = below ? 63 - (int32_t)__clzll((long long)below) : -1;
+                    }
+                    losers &= ~same;
+                }
+                const uint32_t pred_pos = shfl(pos, (uint32_t)(pred < 0 ? 0 : pred));
+                const uint32_t cand = pred >= 0 ? pred_pos : old;
+
+                // the four validity tests of :345-348
+                bool valid = is_probe && active && cand > 0 && cand < pos && (cand + kMaxDist >= pos);
+                u32x4 cnd = {0, 0, 0, 0};
+                if (valid) {
+                    if (have16) cnd = ld128(src + cand); else cnd.x = ld32(src + cand);
+                    valid = cnd.x == fwd.x;
+                }
+                const uint64_t valid_mask = ballot(valid);
+
+                if (valid_mask) {
+                    // ---- match at lane wl (first valid probe, :352) ----
+                    const uint32_t wl = first_lane(valid_mask);
+                    // lanes after the winner never ran in the serial loop: undo their puts, then
+                    // re-commit the last lane <= wl of every duplicate group
+                    if (active && lane > wl) table[h] = (T)old;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    const uint64_t upto = (2ull << wl) - 1ull;   // lanes 0..wl
+                    if (active && lane <= wl && ((grp & upto & ~lanes_below & ~lane_bit) == 0)) table[h] = (T)pos;
+                    // local extension: bytes 4..15 of the two 16-byte reads (:401-413)
+                    uint32_t loc = 0;
+                    bool loc_done = false;
+                    if (lane == wl) {
+                        const uint32_t lim = match_limit - (pos + kMinMatch);   // bytes that may still be compared
+                        if (have16) {
+                            u32x4 a = fwd, b = cnd;
+                            a.x = 0; b.x = 0;
+                            loc = first_diff16(a, b) - 4u;       // 0..12
+                            if (loc >= lim) { loc = lim; loc_done = true; }
+                            else if (loc < 12u) loc_done = true;
+                        }
+                    }
+                    m_pos = rdlane(pos, wl);
+                    m_cand = rdlane(cand, wl);
+                    m_local = rdlane(loc, wl);
+                    m_local_done = rdlane((uint32_t)loc_done, wl) != 0;
+                    found = true;
+                    break;
+                }
+                if (bail_mask) { bailed = true; break; }                // :335-338 -> finishCompression
+                // no match in 64 probes: all puts stand; fix duplicate groups so the last lane's position is stored
+                if (active && grp != lane_bit && ((grp & ~lanes_below & ~lane_bit) == 0)) table[h] = (T)pos;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                ub += 64;
+            }
+            if (bailed || !found) break;
+
+            // ---------------- forward extension (:401-413) ----------------
+            uint32_t mlen = m_local;                                    // matchLength (without MINMATCH)
+            if (!m_local_done) {
+                const uint32_t ip0 = m_pos + kMinMatch, mt0 = m_cand + kMinMatch;
+                for (;;) {
+                    const uint32_t p = ip0 + mlen + lane * 16u;         // first byte this lane compares
+                    uint32_t n = 0;                                     // how many bytes it may compare
+                    if (p < match_limit) n = (match_limit - p) < 16u ? (match_limit - p) : 16u;
+                    uint32_t d = 0;                                     // equal bytes found
+                    if (n > 0) {
+                        const uint32_t q = mt0 + mlen + lane * 16u;
+                        if (p + 16u <= src_size) {
+                            d = first_diff16(ld128(src + p), ld128(src + q));
+                            if (d > n) d = n;
+                        } else {
+                            while (d < n && src[p + d] == src[q + d]) d++;
+                        }
+                    }
+                    const uint64_t stop = ballot(d < 16u);              // mismatch or limit inside this lane's chunk
+                    if (stop) {
+                        const uint32_t sl = first_lane(stop);
+                        mlen += sl * 16u + rdlane(d, sl);
+                        break;
+                    }
+                    mlen += 1024u;
+                }
+            }
+
+            // ---------------- emit the sequence (:360-432) ----------------
+            const uint32_t lit = m_pos - anchor;                        // :360
+            const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
+            const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
+            if (seq_end > dst_len) { failed = true; break; }            // :365-:427 (any of them)
+            if (lane == 0)
+                dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (mlen >= 15u ? 15u : mlen));
+            if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
+            uint8_t *o = dst + op + 1u + nle;
+            copy_bytes(o, src + anchor, lit, lane);                     // :390
+            o += lit;
+            const uint32_t offset = m_pos - m_cand;                     // :395
+            if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));  // :397
+            if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
+            op = (uint32_t)seq_end;
+
+            // ---------------- after the match (:435-442) ----------------
+            const uint32_t end = m_pos + kMinMatch + mlen;
+            anchor = end;
+            if (end < L) { has_ins = true; F0 = end + 1u; }
+            else { has_ins = false; F0 = L; }
+        }
+        res = failed ? kErrOutputTooSmall
+                     : emit_last_literals(dst, dst_len, op, src + anchor, src_size - anchor, lane);   // :337, :446
+    }
+    if (lane == 0) d_result[blk] = res;
+}
+
+}  // namespace zlz4
+
+extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
+                                         const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                         const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks,
+                                         uint32_t max_in_len, uint32_t acceleration) {
+    if (nblocks == 0) return 0;
+    // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
+    if (max_in_len <= 65536u + 11u) {
+        const uint32_t wpw = 4;   // 4 x 8 KiB = 32 KiB LDS per workgroup -> 5 workgroups (20 waves) per CU
+        hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
+                           wpw * 4096 * sizeof(uint16_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
+                           d_out_cap, d_result, nblocks, acceleration);
+    } else {
+        const uint32_t wpw = 2;   // 2 x 16 KiB = 32 KiB LDS per workgroup -> 5 workgroups (10 waves) per CU
+        hipLaunchKernelGGL(zlz4::k_compress_fast<uint32_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
+                           wpw * 4096 * sizeof(uint32_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
+                           d_out_cap, d_result, nblocks, acceleration);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -7;
+}

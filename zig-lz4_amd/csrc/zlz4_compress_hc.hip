@@ -1,0 +1,372 @@
+// zlz4_compress_hc.hip -- LZ4-HC hash-chain compressor (levels 3..9) for gfx950.
+//
+// Replaces lz4hc.compressHC -> compressHCExtState -> compressHashChain
+// (reference src/lz4hc.zig:1440-1489, :976-1064) with its helpers insertHC (:491-510),
+// insertAndGetWiderMatch (:538-681), lz4Count (:234-264), countPattern /
+// reverseCountPattern / isRepetitivePattern (:170-228), encodeSequence (:308-386),
+// encodeLiterals (:1394-1425).  Output is byte-identical to the Zig algorithm
+// (SURVEY.md Appendix A.2, quirks H1-H8).
+//
+// Why this is not a line-by-line port
+// -----------------------------------
+// In the one-shot path the tables start zeroed (Context.init, :405-419) and insertHC
+// inserts EVERY position below the one being searched, whatever the parse did.  So the
+// table state a search at position p sees is a pure function of the input:
+//     hashTable[h(p)]  at the time p is searched = prev(p) = the last q < p with h(q) == h(p)
+//     chainTable[q]                                = min(q - prev(q), 65535)        (prev = 0 if none)
+// That turns the serial insert/search loop into three data-parallel passes:
+//   K1 build_links   one wavefront per block, 32768-entry hash table in LDS, 64 positions per
+//                    step (duplicate hashes inside a step resolved with ballot groups);
+//                    writes link[q] (the chain) to HBM, coalesced.
+//   K2 search        one LANE per position: walks the chain exactly as :571-622 (+ the level-9
+//                    pattern analysis :626-678) and stores the best (len, off) per position.
+//   K3 parse_emit    one wavefront per block: the greedy walk of :1009-1032 over the stored
+//                    results, encodeSequence with its limitedOutput checks, final literals.
+// K2 does redundant work for positions inside matches, but it has 64K-way parallelism per
+// block where the reference has none.
+#include "zlz4_device.hpp"
+
+namespace zlz4 {
+
+constexpr uint32_t kHcHashLog = 15;                 // src/lz4hc.zig:37
+constexpr uint32_t kHcTableSize = 1u << kHcHashLog; // :38
+__device__ __forceinline__ uint32_t hash_hc(uint32_t seq) { return (seq * kHashMul) >> (32 - kHcHashLog); }   // :129-131
+
+// T = uint16_t: blocks whose positions fit 16 bits; link[q] = q - prev(q)  (exact delta, 0 only for q == 0)
+// T = uint32_t: any block;                           link[q] = prev(q)      (0 = none)
+template <typename T> struct Links;
+template <> struct Links<uint16_t> {
+    static __device__ __forceinline__ uint16_t make(uint32_t q, uint32_t prev) { return (uint16_t)(q - prev); }
+    static __device__ __forceinline__ uint32_t first(uint32_t p, uint16_t l) { return p - l; }        // hashTable[h(p)]
+    static __device__ __forceinline__ uint32_t delta(uint32_t, uint16_t l) { return l; }              // chainTable[m]
+};
+template <> struct Links<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(uint32_t, uint32_t prev) { return prev; }
+    static __device__ __forceinline__ uint32_t first(uint32_t, uint32_t l) { return l; }
+    static __device__ __forceinline__ uint32_t delta(uint32_t m, uint32_t l) {                        // :502-503 clamp
+        const uint32_t d = m - l;
+        return d > kMaxDist ? kMaxDist : d;
+    }
+};
+
+// ------------------------------------------------------------------ K1: chain links
+// number of positions that can be searched or inserted: p in [0, n-12]  (:1009 `ip <= mflimit`)
+__device__ __forceinline__ uint32_t n_positions(uint32_t n) { return n < kMfLimit + 1u ? 0u : n - kMfLimit + 1u; }
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict__ d_in,
+                                                        const uint64_t *__restrict__ d_in_off,
+                                                        const uint32_t *__restrict__ d_in_len, T *__restrict__ d_link,
+                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const uint8_t *src = d_in + d_in_off[blk0 + b];
+    const uint32_t n = rfl(d_in_len[blk0 + b]);
+    const uint32_t np = n_positions(n);
+    T *link = d_link + (uint64_t)b * link_stride;
+    volatile T *table = reinterpret_cast<volatile T *>(lds_raw);
+    {
+        u32x4 z = {0, 0, 0, 0};
+        u32x4 *t4 = reinterpret_cast<u32x4 *>(lds_raw);
+        for (uint32_t k = lane; k < kHcTableSize * sizeof(T) / 16u; k += 64u) t4[k] = z;   // Context.init :405-419
+    }
+    const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
+    for (uint32_t base = 0; base < np; base += 64u) {
+        const uint32_t q = base + lane;
+        const bool active = q < np;
+        uint32_t h = 0, old = 0, rb = 0;
+        if (active) {
+            h = hash_hc(ld32(src + q));                 // insertHC :499
+            old = table[h];                             // :500
+            table[h] = (T)q;                            // :505
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (active) rb = table[h];
+        uint64_t losers = ballot(active && rb != (uint32_t)(T)q);
+        uint64_t grp = lane_bit;
+        int32_t pred = -1;
+        while (losers) {                                // one round per duplicate-hash group of this step
+            const uint32_t l = first_lane(losers);
+            const uint32_t hh = rdlane(h, l);
+            const uint64_t same = ballot(active && h == hh);
+            if (active && h == hh) {
+                grp = same;
+                const uint64_t below = same & lanes_below;
+                pred = below ? 63 - (int32_t)__clzll((long long)below) : -1;
+            }
+            losers &= ~same;
+        }
+        if (active) {
+            const uint32_t prev = pred >= 0 ? base + (uint32_t)pred : old;
+            link[q] = Links<T>::make(q, prev);          // :502-504 (clamp applied on read for T = u32)
+            if (grp != lane_bit && (grp & ~lanes_below & ~lane_bit) == 0) table[h] = (T)q;   // last of its group
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------ K2: best match per position
+// lz4Count (:234-264): common prefix length of a.. and b.. with a < limit
+__device__ __forceinline__ uint32_t lz4_count(const uint8_t *src, uint32_t a, uint32_t b, uint32_t limit) {
+    uint32_t c = 0;
+    while (a + 4u <= limit) {
+        const uint32_t x = ld32(src + a) ^ ld32(src + b);
+        if (x) return c + ((uint32_t)__builtin_ctz(x) >> 3);
+        a += 4; b += 4; c += 4;
+    }
+    while (a < limit && src[a] == src[b]) { a++; b++; c++; }
+    return c;
+}
+// countPattern (:170-199) for a pattern that passed isRepetitivePattern (all four bytes equal)
+__device__ __forceinline__ uint32_t count_pattern(const uint8_t *src, uint32_t a, uint32_t end, uint32_t pattern) {
+    uint32_t c = 0;
+    while (a + 4u <= end) {
+        const uint32_t x = ld32(src + a) ^ pattern;
+        if (x) return c + ((uint32_t)__builtin_ctz(x) >> 3);
+        a += 4; c += 4;
+    }
+    const uint8_t pb = (uint8_t)pattern;
+    while (a < end && src[a] == pb) { a++; c++; }
+    return c;
+}
+// reverseCountPattern (:202-222), same restriction; counts bytes equal to the pattern byte below `a`, down to 0
+__device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, uint32_t a, uint32_t pattern) {
+    uint32_t c = 0;
+    const uint8_t pb = (uint8_t)pattern;
+    while (a >= 4u && ld32(src + a - 4u) == pattern) { a -= 4; c += 4; }
+    while (a > 0 && src[a - 1u] == pb) { a--; c++; }
+    return c;
+}
+
+template <typename T, typename R>   // R = packed result: u32 (len | off << 16) for T = u16, u64 (len | off << 32) otherwise
+__global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d_in,
+                                                    const uint64_t *__restrict__ d_in_off,
+                                                    const uint32_t *__restrict__ d_in_len,
+                                                    const T *__restrict__ d_link, uint64_t link_stride,
+                                                    R *__restrict__ d_res, uint32_t blk0, uint32_t nblocks,
+                                                    int32_t max_attempts) {
+    const uint32_t b = blockIdx.y;
+    if (b >= nblocks) return;
+    const uint32_t n = d_in_len[blk0 + b];
+    const uint32_t np = n_positions(n);
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    const uint8_t *src = d_in + d_in_off[blk0 + b];
+    const T *link = d_link + (uint64_t)b * link_stride;
+    const uint32_t limit = n - kLastLiterals;                    // iHighLimit = matchlimit :989, :1011
+    const bool pattern_analysis = max_attempts > 128;            // :983
+
+    // insertAndGetWiderMatch with iLowLimit == ip, longest = MINMATCH-1 (:522-534)
+    const uint32_t lowest = p < 65536u ? 0u : p - kMaxDist;      // :553-554 (lowLimit == 0)
+    const uint32_t pattern = ld32(src + p);                      // :558
+    int32_t best_len = (int32_t)kMinMatch - 1;                   // :560
+    uint32_t best_off = 0;
+    uint32_t m = Links<T>::first(p, link[p]);                    // :563  hashTable[hashPtr(ip)]
+    if (m != 0) {                                                // :566-568
+        int32_t nb = max_attempts;
+        while (m > 0 && nb > 0) {                                // :571
+            if (m > p || (p - m) > kMaxDist) break;              // :573
+            nb -= 1;                                             // :577
+            if (m >= lowest) {                                   // :579
+                if (ld32(src + m) == pattern) {                  // :586
+                    const int32_t mlt = (int32_t)(kMinMatch + lz4_count(src, p + kMinMatch, m + kMinMatch, limit));
+                    // back == 0: `ip > iLowLimit` is false (:596)
+                    if (mlt > best_len) {                        // :607
+                        best_len = mlt;
+                        best_off = p - m;
+                        if (mlt > max_attempts) break;           // :613
+                    }
+                }
+            }
+            const uint32_t delta = Links<T>::delta(m, link[m]);  // :619
+            if (delta == 0 || delta > m) break;                  // :620
+            m -= delta;                                          // :621
+        }
+        if (pattern_analysis && best_len > 0) {                  // :626
+            const uint32_t delta = Links<T>::delta(m, link[m]);  // :627 (m == 0 -> link[0] -> delta 0)
+            if (delta == 1 && ((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {   // :629-631
+                const uint32_t src_pat_len = count_pattern(src, p + 4u, limit, pattern) + 4u;   // :633
+                const uint32_t cand = m - 1u;                    // :636
+                if (cand >= lowest) {                            // :637 (dictIdx == 0)
+                    if (ld32(src + cand) == pattern) {           // :644
+                        const uint32_t fwd_len = count_pattern(src, cand + 4u, limit, pattern) + 4u;   // :646
+                        const uint32_t back_len = reverse_count_pattern(src, cand, pattern);           // :650
+                        uint32_t lo = cand - back_len;           // :653
+                        if (lo < lowest) lo = lowest;
+                        const uint32_t lim_back = cand - lo;
+                        const uint32_t seg_len = lim_back + fwd_len;                                   // :654
+                        const int32_t max_ml = (int32_t)(seg_len < src_pat_len ? seg_len : src_pat_len);   // :658
+                        uint32_t new_m;
+                        if (seg_len >= src_pat_len && fwd_len <= src_pat_len) new_m = cand + fwd_len - src_pat_len;   // :660-662
+                        else new_m = cand - lim_back;            // :665
+                        if (max_ml > best_len && (p - new_m) <= kMaxDist) {   // :669
+                            best_len = max_ml;
+                            best_off = p - new_m;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    R r;
+    if (sizeof(R) == 4) r = (R)((uint32_t)best_len | (best_off << 16));
+    else r = (R)((uint64_t)(uint32_t)best_len | ((uint64_t)best_off << 32));
+    d_res[(uint64_t)b * link_stride + p] = r;
+}
+
+// ------------------------------------------------------------------ K3: greedy parse + emit
+template <typename R>
+__global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict__ d_in,
+                                                        const uint64_t *__restrict__ d_in_off,
+                                                        const uint32_t *__restrict__ d_in_len,
+                                                        uint8_t *__restrict__ d_out,
+                                                        const uint64_t *__restrict__ d_out_off,
+                                                        const uint32_t *__restrict__ d_out_cap,
+                                                        int64_t *__restrict__ d_result, const R *__restrict__ d_res,
+                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (b >= nblocks) return;
+    const uint32_t blk = blk0 + b;
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t n = rfl(d_in_len[blk]);
+    const uint32_t oend = rfl(d_out_cap[blk]);
+    const R *res = d_res + (uint64_t)b * link_stride;
+
+    int64_t out;
+    if (n > kMaxInput) {                                         // :1442
+        out = kErrInputTooLarge;
+    } else if (n == 0) {                                         // :1443
+        out = 0;
+    } else if (oend == 0) {                                      // :1461
+        out = kErrOutputTooSmall;
+    } else if (n < kMfLimit + 1u) {                              // :995-998 encodeLiterals (:1394-1425)
+        if (oend < n + 1u + n / 255u) out = kErrOutputTooSmall;  // :1395
+        else {
+            if (lane == 0) dst[0] = (uint8_t)(n << 4);           // n < 13 < 15
+            if (lane < n) dst[1u + lane] = src[lane];
+            out = (int64_t)n + 1;
+        }
+    } else {
+        const uint32_t mflimit = n - kMfLimit;                   // :988
+        uint32_t ip = 0, anchor = 0, op = 0;
+        bool failed = false;
+        // 64-position window of search results held in registers
+        uint32_t wbase = 0;
+        R w = (lane <= mflimit) ? res[lane] : (R)0;
+        while (ip <= mflimit) {                                  // :1009
+            if (ip - wbase >= 64u) {
+                wbase = ip;
+                w = (ip + lane <= mflimit) ? res[ip + lane] : (R)0;
+            }
+            uint32_t len, off;
+            if (sizeof(R) == 4) {
+                const uint32_t r = rdlane((uint32_t)w, ip - wbase);
+                len = r & 0xFFFFu; off = r >> 16;
+            } else {
+                len = rdlane((uint32_t)w, ip - wbase);
+                off = rdlane((uint32_t)((uint64_t)w >> 32), ip - wbase);
+            }
+            if (len < kMinMatch || off == 0) { ip += 1; continue; }   // :1013-1016
+            // encodeSequence (:308-386) with limitedOutput
+            const uint32_t lit = ip - anchor;                    // :317
+            if ((uint64_t)op + lit / 255u + lit + (2u + 1u + kLastLiterals) > oend) { failed = true; break; }   // :320-325
+            const uint32_t ml_code = len - kMinMatch;            // :354
+            const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(ml_code);
+            const uint32_t op2 = op + 1u + nle + lit + 2u;       // after token, literal length, literals, offset
+            if ((uint64_t)op2 + ml_code / 255u + (1u + kLastLiterals) > oend) { failed = true; break; }   // :355-359
+            if (lane == 0)
+                dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (ml_code >= 15u ? 15u : ml_code));
+            if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
+            copy_bytes(dst + op + 1u + nle, src + anchor, lit, lane);   // :346
+            if (lane < 2u) dst[op2 - 2u + lane] = (uint8_t)(off >> (8u * lane));   // :350
+            if (ml_code >= 15u) write_ext_len(dst + op2, ml_code, lane);           // :361-376 (510-steps == 255-run)
+            op = op2 + nme;
+            ip += len;                                           // :382
+            anchor = ip;
+        }
+        if (failed) {
+            out = kErrOutputTooSmall;                            // :1029-1031
+        } else {
+            const uint32_t fl = n - anchor;                      // :1035
+            out = (int64_t)op;
+            if (fl > 0) {
+                const uint32_t nle = ext_len_bytes(fl);
+                // :1037 tests only op + fl + 1; the reference then writes the length-extension bytes
+                // unchecked (out of bounds when they do not fit).  We refuse instead of overrunning.
+                if ((uint64_t)op + fl + 1u > oend || (uint64_t)op + 1u + nle + fl > oend) out = kErrOutputTooSmall;
+                else {
+                    if (lane == 0) dst[op] = (uint8_t)((fl >= 15u ? 15u : fl) << 4);
+                    if (fl >= 15u) write_ext_len(dst + op + 1u, fl, lane);
+                    copy_bytes(dst + op + 1u + nle, src + anchor, fl, lane);   // :1059
+                    out = (int64_t)(op + 1u + nle + fl);
+                }
+            }
+        }
+    }
+    if (lane == 0) d_result[blk] = out;
+}
+
+template <typename T, typename R>
+int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                      uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, int64_t *d_result,
+                      uint32_t nblocks, uint32_t max_in_len, int32_t max_attempts, void *ws, uint32_t chunk) {
+    const uint64_t stride = ((uint64_t)max_in_len + 15u) & ~15ull;           // entries per block in both arrays
+    T *d_link = static_cast<T *>(ws);
+    R *d_res = reinterpret_cast<R *>(static_cast<uint8_t *>(ws) + (uint64_t)chunk * stride * sizeof(T));
+    const uint32_t np_max = max_in_len < 13u ? 1u : max_in_len - 11u;
+    if (kHcTableSize * sizeof(T) > 65536u)   // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * sizeof(T)));
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
+        const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+        hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
+                           d_in_len, d_link, stride, b0, nb);
+        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 255u) / 256u, nb), dim3(256), 0, stream, d_in, d_in_off,
+                           d_in_len, d_link, stride, d_res, b0, nb, max_attempts);
+        hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
+                           d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -7;
+}
+
+}  // namespace zlz4
+
+namespace {
+constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per K1/K2/K3 round (bounds the workspace)
+bool hc_small(uint32_t max_in_len) { return max_in_len <= 65536u; }
+uint32_t hc_chunk(uint32_t nblocks, uint32_t max_in_len) {
+    // keep a round's workspace around <= 2 GiB for big blocks
+    const uint64_t per = (((uint64_t)max_in_len + 15u) & ~15ull) * (hc_small(max_in_len) ? 6u : 12u);
+    uint64_t c = (2ull << 30) / (per ? per : 1);
+    if (c < 1) c = 1;
+    if (c > kHcChunkBlocks) c = kHcChunkBlocks;
+    if (c > nblocks) c = nblocks ? nblocks : 1;
+    return (uint32_t)c;
+}
+}  // namespace
+
+extern "C" size_t zlz4_hc_workspace_bytes(uint32_t nblocks, uint32_t max_in_len) {
+    const uint64_t stride = ((uint64_t)max_in_len + 15u) & ~15ull;
+    return (size_t)(hc_chunk(nblocks, max_in_len) * stride * (hc_small(max_in_len) ? 6u : 12u));
+}
+
+// src/lz4hc.zig:72-86: levels 3..9 -> nbSearches 4..256
+extern "C" int zlz4_launch_compress_hc(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
+                                       const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                       const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks,
+                                       uint32_t max_in_len, int32_t level, void *ws, size_t ws_bytes) {
+    if (nblocks == 0) return 0;
+    if (level < 3 || level > 9) return -8;
+    if (ws_bytes < zlz4_hc_workspace_bytes(nblocks, max_in_len)) return -5;
+    const int32_t max_attempts = 1 << (level - 1);   // 3 -> 4 ... 9 -> 256
+    const uint32_t chunk = hc_chunk(nblocks, max_in_len);
+    if (hc_small(max_in_len))
+        return zlz4::launch_hc_chunked<uint16_t, uint32_t>(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                                           d_result, nblocks, max_in_len, max_attempts, ws, chunk);
+    return zlz4::launch_hc_chunked<uint32_t, uint64_t>(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                                       d_result, nblocks, max_in_len, max_attempts, ws, chunk);
+}

@@ -1,0 +1,130 @@
+// zlz4_decompress.hip -- LZ4 block decoder for gfx950, one wavefront per block.
+//
+// Replaces lz4.decompressSafe (reference src/lz4.zig:257-259), i.e.
+// decompressGeneric (src/lz4.zig:89-251) with lowPrefix == dst.ptr and no
+// dictionary.  The decision order and the error returned at every exit follow
+// SURVEY.md Appendix C exactly; `dst` contents after an error are unspecified
+// (as in the reference).
+//
+// Layout: the token stream is parsed wave-uniformly out of a 64-byte register
+// window (lane i holds src[wbase + i], tokens/lengths/offsets are pulled with
+// v_readlane), short literal runs are stored straight from that window, long
+// ones and matches are copied 16 B per lane.  Overlapping matches
+// (offset < matchLength, src/lz4.zig:235-241) use the periodic-extension
+// identity out[op+k] = out[op-offset + (k mod offset)].
+#include "zlz4_device.hpp"
+
+namespace zlz4 {
+
+__global__ __launch_bounds__(256) void k_decompress_safe(
+    const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
+    const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
+    const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (blk >= nblocks) return;
+
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t iend = rfl(d_in_len[blk]);   // src.len
+    const uint32_t oend = rfl(d_out_cap[blk]);  // dst.len == targetOutputSize
+
+    int64_t res = 0;
+    uint32_t ip = 0, op = 0;
+
+    if (iend != 0 && oend != 0) {               // src/lz4.zig:97-98
+        // 64-byte register window over the compressed stream
+        uint32_t wbase = 0;
+        uint32_t w = (lane < iend) ? src[lane] : 0u;
+        auto reload = [&](uint32_t pos) {
+            wbase = pos;
+            w = (pos + lane < iend) ? src[pos + lane] : 0u;
+        };
+        auto fetch = [&](uint32_t pos) -> uint32_t {   // caller guarantees pos < iend
+            if (pos - wbase >= 64u) reload(pos);
+            return rdlane(w, pos - wbase);
+        };
+
+        for (;;) {
+            if (ip >= iend) break;                                  // :113
+            const uint32_t token = fetch(ip);                       // :116
+            ip += 1;
+            uint32_t lit = token >> 4;                              // :120
+            if (lit == 15u) {                                       // :123-131
+                bool bad = false;
+                for (;;) {
+                    if (ip >= iend) { bad = true; break; }          // :125
+                    const uint32_t s = fetch(ip);
+                    ip += 1;
+                    lit += s;
+                    if (s != 255u) break;
+                }
+                if (bad) { res = kErrCorrupted; break; }
+            }
+            if (lit > 0) {                                          // :134
+                if ((uint64_t)ip + lit > iend) { res = kErrCorrupted; break; }        // :136
+                if ((uint64_t)op + lit > oend) { res = kErrOutputTooSmall; break; }   // :137
+                if (lit <= 64u) {
+                    if (ip - wbase + lit > 64u) reload(ip);
+                    const uint32_t j0 = ip - wbase;
+                    if (lane >= j0 && lane < j0 + lit) dst[op + (lane - j0)] = (uint8_t)w;
+                } else {
+                    copy_bytes(dst + op, src + ip, lit, lane);      // :140
+                }
+                ip += lit;
+                op += lit;
+            }
+            if (ip >= iend) break;                                  // :146
+            if (ip + 2u > iend) { res = kErrCorrupted; break; }     // :149
+            const uint32_t offset = fetch(ip) | (fetch(ip + 1u) << 8);   // :150
+            ip += 2;
+            if (offset == 0) { res = kErrCorrupted; break; }        // :154
+            uint32_t ml = token & 15u;                              // :157
+            if (ml == 15u) {                                        // :160-168
+                bool bad = false;
+                for (;;) {
+                    if (ip >= iend) { bad = true; break; }          // :162
+                    const uint32_t s = fetch(ip);
+                    ip += 1;
+                    ml += s;
+                    if (s != 255u) break;
+                }
+                if (bad) { res = kErrCorrupted; break; }
+            }
+            ml += kMinMatch;                                        // :171
+            if ((uint64_t)op + ml > oend) { res = kErrOutputTooSmall; break; }   // :174
+            if (offset > op) { res = kErrCorrupted; break; }        // :181-186 (no dict) / :231
+            const uint8_t *m = dst + (op - offset);
+            uint8_t *o = dst + op;
+            if (offset >= ml || offset >= 1024u) {
+                // disjoint, or far enough apart that 1 KiB chunks in address order are exact (:244 / :238-240)
+                copy_bytes(o, m, ml, lane);
+            } else if (offset >= 64u) {
+                for (uint32_t k = lane; k < ml; k += 64u) o[k] = m[k];
+            } else {
+                // RLE-style overlap: every output byte is m[k mod offset]; with a chunk that is a
+                // multiple of `offset` each lane's value is loop-invariant.
+                const uint32_t cs = 64u - (64u % offset);
+                const uint8_t v = m[lane % offset];
+                if (lane < cs)
+                    for (uint32_t k = lane; k < ml; k += cs) o[k] = v;
+            }
+            op += ml;
+        }
+        if (res == 0) res = (int64_t)op;                            // :250
+    }
+    if (lane == 0) d_result[blk] = res;
+}
+
+}  // namespace zlz4
+
+extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
+                                           const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                           const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks) {
+    if (nblocks == 0) return 0;
+    const uint32_t waves_per_wg = 4;
+    const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
+    hipLaunchKernelGGL(zlz4::k_decompress_safe, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
+                       d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+    return hipGetLastError() == hipSuccess ? 0 : -7;
+}
