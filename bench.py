@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X LZ4 block codec on BASELINE.json's configs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4] [--dist text|...]
+
+Default workload = BASELINE.json configs[1]: 65 536 independent 64 KiB blocks (4 GiB),
+compressDefault, then decompressSafe of the result (the metric is "block
+compress+decompress").  One step = one pass of both kernels over the batch; inputs are
+resident in HBM before the timed region.  `value` = uncompressed GiB processed per second
+by the whole job (all ranks), over compress+decompress time (round trip); the per-kernel
+rates are reported next to it.  For N > 1 every rank runs the same per-GPU batch on its
+own data (independent blocks: no collective on the data path, weak scaling).
+
+The JSON line also carries
+  roofline      for the dominant kernel (compress): algorithmic bytes (N read + C written)
+                per launch / average launch duration from HIP events on the launch stream,
+                against the 8 TB/s HBM3E peak;
+  cpu_baseline  oracle/ (C restatement of the reference, "port") timed on this box's host
+                cores on a bounded sample of the same blocks (rank 0, N == 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GIB = float(1 << 30)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_device_blocks(dist, nblocks, block_size, dev, seed):
+    """[nblocks, block_size] uint8 on the device, every block distinct.
+
+    text: a CPU-generated pool (tests/datagen.py) is expanded on the GPU by giving every
+    repetition its own random byte-substitution table -- LZ4's behaviour is invariant under
+    a bijection of byte values, so all repetitions have the statistics of the pool while no
+    two blocks hold the same bytes (no cache aliasing between them)."""
+    import datagen as dg
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000 + seed)
+    if dist == "zero":
+        return torch.zeros((nblocks, block_size), dtype=torch.uint8, device=dev)
+    if dist == "ramp":
+        row = (torch.arange(block_size, device=dev) % 256).to(torch.uint8)
+        return row.unsqueeze(0).repeat(nblocks, 1).contiguous()
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(2000 + seed)
+    if dist == "random":
+        return torch.randint(0, 256, (nblocks, block_size), dtype=torch.uint8, device=dev, generator=gd)
+    if dist == "mixed":
+        t = torch.randint(0, 256, (nblocks, block_size), dtype=torch.uint8, device=dev, generator=gd)
+        t[:, : block_size // 2] = ord("X")
+        return t
+    assert dist == "text"
+    pool_blocks = min(nblocks, max(1, (32 << 20) // block_size))
+    pool = torch.from_numpy(dg.make_blocks("text", pool_blocks, block_size, seed=seed)).to(dev)
+    out = torch.empty((nblocks, block_size), dtype=torch.uint8, device=dev)
+    done, rep = 0, 0
+    idx = pool.long()
+    while done < nblocks:
+        n = min(pool_blocks, nblocks - done)
+        lut = torch.randperm(256, generator=g).to(torch.uint8).to(dev) if rep else torch.arange(256, dtype=torch.uint8, device=dev)
+        shift = (rep * 7919) % pool_blocks
+        src = torch.roll(idx, shifts=shift, dims=0)[:n] if shift else idx[:n]
+        out[done:done + n] = lut[src]
+        done += n
+        rep += 1
+    del idx
+    return out
+
+
+def cpu_baseline(sample_blocks, block_size, slot, hc_level=None):
+    """Time the oracle (C restatement of the reference) on host cores: 1 thread and all cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as ob
+    L = ob.lib()
+    data = np.ascontiguousarray(sample_blocks)
+    nb = data.shape[0]
+    comp = np.zeros(nb * slot, dtype=np.uint8)
+    sizes = np.zeros(nb, dtype=np.int64)
+    dec = np.zeros(nb * block_size, dtype=np.uint8)
+    dsz = np.zeros(nb, dtype=np.int64)
+
+    def run(lo, hi):
+        n = hi - lo
+        if hc_level is None:
+            L.zo_batch_compress_default(data[lo:].ctypes.data, block_size, n, comp[lo * slot:].ctypes.data, slot,
+                                        sizes[lo:].ctypes.data)
+        else:
+            L.zo_batch_compress_hc(data[lo:].ctypes.data, block_size, n, comp[lo * slot:].ctypes.data, slot,
+                                   sizes[lo:].ctypes.data, hc_level)
+
+    def rund(lo, hi):
+        L.zo_batch_decompress_safe(comp[lo * slot:].ctypes.data, slot, sizes[lo:].ctypes.data, hi - lo,
+                                   dec[lo * block_size:].ctypes.data, block_size, dsz[lo:].ctypes.data)
+
+    t0 = time.perf_counter(); run(0, nb); tc1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); rund(0, nb); td1 = time.perf_counter() - t0
+    assert (dec.reshape(nb, block_size) == data).all(), "oracle round trip failed"
+    ncores = min(os.cpu_count() or 1, 64)
+    try:
+        ncores = min(ncores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    parts = [(i * nb // ncores, (i + 1) * nb // ncores) for i in range(ncores)]
+    with ThreadPoolExecutor(ncores) as ex:     # ctypes releases the GIL inside the C calls
+        t0 = time.perf_counter(); list(ex.map(lambda p: run(*p), parts)); tcn = time.perf_counter() - t0
+        t0 = time.perf_counter(); list(ex.map(lambda p: rund(*p), parts)); tdn = time.perf_counter() - t0
+    nbytes = nb * block_size
+    return {
+        "value": nbytes / (tc1 + td1) / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
+        "sample": "%d of the benchmark's %d-byte blocks (%.0f MiB): oracle/ compress then decompress, 1 thread"
+                  % (nb, block_size, nbytes / 2**20),
+        "compress_gibs": nbytes / tc1 / GIB, "decompress_gibs": nbytes / td1 / GIB,
+        "all_cores": {"cores": ncores, "value": nbytes / (tcn + tdn) / GIB,
+                      "compress_gibs": nbytes / tcn / GIB, "decompress_gibs": nbytes / tdn / GIB},
+        "compressed_sizes_head": [int(x) for x in sizes[:4]],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--dist", default="text", choices=["text", "ramp", "mixed", "random", "zero"])
+    ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-sample-mib", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import zig_lz4_amd as zl     # raises if libzlz4_amd.so is missing: no fallback
+    if not zl.device_available():
+        raise SystemExit("libzlz4_amd.so: no usable gfx950 device")
+
+    block = 65536
+    defaults = {"cfg2": 65536, "cfg3": 1 << 20, "cfg4": 16384}
+    nblocks = args.blocks or defaults[args.workload]
+    hc_level = 9 if args.workload == "cfg4" else None
+    slot = (zl.compressBound(block) + 15) // 16 * 16          # 65 809 -> 65 824
+    names = {
+        "cfg2": "configs[1]: %d x 64 KiB blocks, compressDefault then decompressSafe (round trip), D-%s",
+        "cfg3": "configs[2]: decompressSafe only, %d pre-compressed 64 KiB blocks, D-%s",
+        "cfg4": "configs[3]: compressHC level 9 then decompressSafe, %d x 64 KiB blocks, D-%s",
+    }
+    workload = names[args.workload] % (nblocks, args.dist)
+
+    t0 = time.time()
+    inp = make_device_blocks(args.dist, nblocks, block, dev, seed=rank + 1)
+    torch.cuda.synchronize()
+    log("[rank %d] generated %.2f GiB of D-%s in %.1f s" % (rank, nblocks * block / GIB, args.dist, time.time() - t0))
+
+    ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
+    in_off = ar * block
+    in_len = torch.full((nblocks,), block, dtype=torch.int32, device=dev)
+    slot_off = ar * slot
+    slot_cap = torch.full((nblocks,), slot, dtype=torch.int32, device=dev)
+    comp = torch.empty(nblocks * slot, dtype=torch.uint8, device=dev)
+    csize = torch.empty(nblocks, dtype=torch.int64, device=dev)
+    out = torch.empty((nblocks, block), dtype=torch.uint8, device=dev)
+    dsize = torch.empty(nblocks, dtype=torch.int64, device=dev)
+    ws = None
+    if hc_level is not None:
+        ws = torch.empty(zl.batch_compress_hc_workspace(nblocks, block), dtype=torch.uint8, device=dev)
+
+    def do_compress():
+        if hc_level is None:
+            zl.batch_compress_fast(inp, in_off, in_len, comp, slot_off, slot_cap, csize, block, 1)
+        else:
+            zl.batch_compress_hc(inp, in_off, in_len, comp, slot_off, slot_cap, csize, block, hc_level, ws)
+
+    clen32 = None
+
+    def do_decompress():
+        zl.batch_decompress_safe(comp, slot_off, clen32, out, in_off, in_len, dsize)
+
+    # untimed first pass: produces the compressed batch and checks the round trip
+    do_compress()
+    torch.cuda.synchronize()
+    assert int(csize.min()) > 0, "compress reported an error: %d" % int(csize.min())
+    clen32 = csize.to(torch.int32)
+    do_decompress()
+    torch.cuda.synchronize()
+    assert bool((dsize == block).all()), "decompress size mismatch"
+    assert torch.equal(out, inp), "round trip mismatch"
+    total_c = int(csize.sum())
+    total_n = nblocks * block
+    log("[rank %d] round trip ok, ratio %.3f" % (rank, total_n / total_c))
+
+    decomp_only = args.workload == "cfg3"
+    for _ in range(args.warmup):
+        if not decomp_only:
+            do_compress()
+        do_decompress()
+    torch.cuda.synchronize()
+    if dist_on:
+        td.barrier()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        if not decomp_only:
+            do_compress()
+        ev[k][1].record()
+        do_decompress()
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    if dist_on:
+        td.barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tc_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
+    td_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+
+    if rank == 0:
+        value = world * total_n * args.steps / elapsed / GIB
+        comp_gibs = None if decomp_only else total_n / (tc_ms * 1e-3) / GIB
+        dec_gibs = total_n / (td_ms * 1e-3) / GIB
+        if decomp_only:
+            dom, dom_ms = "zlz4::k_decompress_safe", td_ms
+        else:
+            dom, dom_ms = ("zlz4::k_compress_fast<uint16_t>" if hc_level is None else "zlz4::k_hc_search"), tc_ms
+        achieved = (total_n + total_c) / (dom_ms * 1e-3) / 1e9
+        res = {
+            "metric": "GiB/s uncompressed, block compress+decompress",
+            "value": value, "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload, "blocks_per_gpu": nblocks, "block_bytes": block,
+                       "uncompressed_bytes_per_gpu": total_n, "compressed_bytes_per_gpu": total_c,
+                       "ratio": total_n / total_c, "distribution": "D-" + args.dist,
+                       "sharding": "independent blocks, contiguous range per GPU, no collective"},
+            "compress_gibs_per_gpu": comp_gibs, "decompress_gibs_per_gpu": dec_gibs,
+            "compress_ms": None if decomp_only else tc_ms, "decompress_ms": td_ms,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": total_n + total_c, "avg_launch_ms": dom_ms},
+            "roofline_decompress": {"bound": "hbm", "kernel": "zlz4::k_decompress_safe",
+                                    "achieved": (total_n + total_c) / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": (total_n + total_c) / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "traffic": None, "avg_launch_ms": td_ms},
+        }
+        if world == 1 and not args.no_cpu:
+            mib = args.cpu_sample_mib or (1024 if hc_level is None else 96)
+            nsamp = max(1, min(nblocks, mib * (1 << 20) // block))
+            sample = inp[:nsamp].cpu().numpy()
+            cb = cpu_baseline(sample, block, slot, hc_level)
+            # the same sample through the HIP path must give the same compressed sizes
+            assert cb["compressed_sizes_head"] == [int(x) for x in csize[:4].cpu()], "HIP vs oracle size mismatch"
+            res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    if dist_on:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
