@@ -13,10 +13,14 @@ all: $(LIB) oracle
 $(LIB): $(HIPSRC) $(CSRC)/zlz4_device.hpp include/zlz4_amd.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)
 
+# diagnostic build: per-phase cycle stamps inside the compress kernel (never shipped / never benchmarked)
+stamps: $(HIPSRC) $(CSRC)/zlz4_device.hpp include/zlz4_amd.h
+	$(HIPCC) $(HIPFLAGS) -DZLZ4_STAMPS -shared -o $(PKG)/libzlz4_amd_stamps.so $(HIPSRC)
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
 	rm -f $(LIB)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean stamps

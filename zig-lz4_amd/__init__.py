@@ -13,7 +13,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzlz4_amd.so")
+# ZLZ4_AMD_LIB selects a diagnostic build of the same library (e.g. the -DZLZ4_STAMPS one); never a fallback
+LIB_PATH = os.environ.get("ZLZ4_AMD_LIB") or os.path.join(_HERE, "libzlz4_amd.so")
 
 # constants re-exported by src/root.zig:46-49 and src/lz4hc.zig:28-31
 MINMATCH = 4

@@ -26,7 +26,25 @@
 // duplicate-hash group) plus one ballot per duplicate group.  The first valid lane
 // wins (ballot + ffs); lanes after it put their old table value back, so the table
 // ends up exactly as the serial loop would have left it.
+#include <cstdlib>
+
 #include "zlz4_device.hpp"
+
+// Diagnostic build only (-DZLZ4_STAMPS): per-phase shader-cycle sums, see profiles/ notes.
+#ifdef ZLZ4_STAMPS
+__device__ unsigned long long g_zlz4_stamps[16];
+#define STAMP_DECL unsigned long long st_acc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); \
+                      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define STAMP_COUNT(i) do { st_acc[i] += 1; } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int st_k = 0; st_k < 10; st_k++) atomicAdd(&g_zlz4_stamps[st_k], st_acc[st_k]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_COUNT(i)
+#define STAMP_FLUSH
+#endif
 
 namespace zlz4 {
 
@@ -48,6 +66,35 @@ __device__ __forceinline__ int64_t emit_last_literals(uint8_t *dst, uint32_t dst
     if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
     copy_bytes(dst + op + 1u + nle, lit_src, lit, lane);
     return (int64_t)(op + 1u + nle + lit);
+}
+
+// Wave-cooperative forward extension (:401-413): continues from `mlen` equal bytes after the 4 MINMATCH
+// bytes, 16 B per lane (1 KiB per step), first mismatch or the srcSize-5 limit found with ballot + ffs.
+__device__ __forceinline__ uint32_t extend_match(const uint8_t *__restrict__ src, uint32_t m_pos, uint32_t m_cand,
+                                                 uint32_t mlen, uint32_t match_limit, uint32_t src_size,
+                                                 uint32_t lane) {
+    const uint32_t ip0 = m_pos + kMinMatch, mt0 = m_cand + kMinMatch;
+    for (;;) {
+        const uint32_t p = ip0 + mlen + lane * 16u;         // first byte this lane compares
+        uint32_t n = 0;                                     // how many bytes it may compare
+        if (p < match_limit) n = (match_limit - p) < 16u ? (match_limit - p) : 16u;
+        uint32_t d = 0;                                     // equal bytes found
+        if (n > 0) {
+            const uint32_t q = mt0 + mlen + lane * 16u;
+            if (p + 16u <= src_size) {
+                d = first_diff16(ld128(src + p), ld128(src + q));
+                if (d > n) d = n;
+            } else {
+                while (d < n && src[p + d] == src[q + d]) d++;
+            }
+        }
+        const uint64_t stop = ballot(d < 16u);              // mismatch or limit inside this lane's chunk
+        if (stop) {
+            const uint32_t sl = first_lane(stop);
+            return mlen + sl * 16u + rdlane(d, sl);
+        }
+        mlen += 1024u;
+    }
 }
 
 template <typename T>   // T = uint16_t when every stored position fits 16 bits, else uint32_t
@@ -97,10 +144,198 @@ __global__ __launch_bounds__(256) void k_compress_fast(
         uint32_t F0 = 1;                                                // :317
         bool has_ins = false;    // pending put(anchor) of :438-441, folded into the next batch as lane 0
         bool failed = false;
+        STAMP_DECL
+        STAMP(0);   // table init
 
         while (F0 < L) {                                                // :320
-            // ---------------- search: 64 probes per step ----------------
-            int32_t ub = -1;      // probe index of lane 0 (-1 = the pending insert pseudo-probe)
+            int32_t ub = -1;      // probe index of lane 0 of the next generic batch (-1 = pending insert pseudo-probe)
+
+            // =====================================================================================
+            // Window path (acceleration 1, away from the end of the block): lane i <-> position
+            // anchor + i.  Every search that starts inside the window probes consecutive positions
+            // (the first 66 probes of a search have stride 1), so all sequences that begin in these
+            // 64 positions are resolved from registers: one 16-byte forward load per lane, one table
+            // read / speculative put / read-back, one candidate gather -- then one short loop
+            // iteration per sequence.  `ins` = lanes the serial loop would have put() so far; a lane's
+            // table read is its nearest earlier `ins` lane with the same hash, else the pre-window
+            // value.  At the end lanes not in `ins` put their old value back.
+            // =====================================================================================
+            if (accel == 1u && F0 == anchor + 1u && (has_ins || anchor == 0u) && (uint64_t)anchor + 192u < L) {
+                const uint32_t A = anchor;
+                const uint32_t pos = A + lane;
+                const bool wr = has_ins || lane > 0;                    // position 0 is never inserted (Q1)
+                const u32x4 fwd = ld128(src + pos);
+                const uint32_t h = hash4(fwd.x);                        // :341
+                STAMP(1);
+                STAMP_COUNT(8);
+                uint32_t old = 0, rb = 0;
+                if (wr) {
+                    old = table[h];                                     // :342
+                    table[h] = (T)pos;                                  // :350 (speculative)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (wr) rb = table[h];
+                uint64_t losers = ballot(wr && rb != (uint32_t)(T)pos);
+                uint64_t grp = lane_bit;
+                while (losers) {                                        // one round per duplicate-hash group
+                    const uint32_t l = first_lane(losers);
+                    const uint32_t hh = rdlane(h, l);
+                    const uint64_t same = ballot(wr && h == hh);
+                    if (wr && h == hh) grp = same;
+                    losers &= ~same;
+                }
+                STAMP(2);
+                // pre-window candidates: the old table value passes `match > 0`, `match < ip` (always) and
+                // the distance test (:345-347); its bytes are gathered once for the whole window
+                const bool old_ok = wr && old > 0 && (old + kMaxDist >= pos);
+                u32x4 cold = {0, 0, 0, 0};
+                if (old_ok) cold = ld128(src + old);
+                STAMP(3);
+
+                // What a probe at lane i finds if its table slot still holds the pre-window value: validity
+                // (:345-348), the first 12 bytes of forward extension (:401-413) and the offset.  For a lane
+                // whose hash is unique in the window this does not depend on the parse at all.
+                const bool vo = old_ok && cold.x == fwd.x;
+                uint32_t mlo;
+                {
+                    const uint32_t x1 = fwd.y ^ cold.y, x2 = fwd.z ^ cold.z, x3 = fwd.w ^ cold.w;
+                    mlo = x1 ? (uint32_t)__builtin_ctz(x1) >> 3
+                             : (x2 ? 4u + ((uint32_t)__builtin_ctz(x2) >> 3)
+                                   : (x3 ? 8u + ((uint32_t)__builtin_ctz(x3) >> 3) : 12u));
+                }
+                const bool single = grp == lane_bit;
+                const uint64_t vind = ballot(vo && single && mlo < 12u);          // resolved by scalar code alone
+                const uint64_t slow = ballot(wr && (!single || (vo && mlo >= 12u)));   // need the exact per-lane step
+
+                uint64_t ins = has_ins ? 1ull : 0ull;
+                uint32_t f = 1;          // lane where the current search starts
+                uint32_t a = 0;          // lane of the current anchor
+                uint64_t skip = 0;       // slow lanes already probed (and failed) in the current search
+                uint64_t lits_mask = 0, match_mask = 0;      // deferred emission of the simple sequences
+                uint32_t v_base = 0, v_opk = 0, v_lit = 0;
+                bool continue_generic = false;
+                for (;;) {
+                    const uint64_t rem = ~((1ull << f) - 1ull);                 // lanes >= f
+                    const uint64_t c_fast = vind & rem, c_slow = slow & rem & ~skip;
+                    const uint32_t jf = c_fast ? first_lane(c_fast) : 64u;
+                    const uint32_t js = c_slow ? first_lane(c_slow) : 64u;
+                    uint32_t j, mlen;
+                    if (jf < js) {
+                        // ---- first valid probe is a hash-unique lane: everything is already in registers ----
+                        j = jf;
+                        mlen = rdlane(mlo, j);
+                        const uint32_t lit = j - a;
+                        const uint64_t lit_lanes = ((1ull << j) - 1ull) & ~((1ull << a) - 1ull);
+                        if (lit < 15u) {
+                            if (op + 3u + lit > dst_len) { failed = true; break; }
+                            const bool is_l = (lit_lanes & lane_bit) != 0, is_j = lane == j;
+                            v_base = is_l ? op + 1u - a : v_base;
+                            v_opk = is_j ? op : v_opk;
+                            v_lit = is_j ? lit : v_lit;
+                            lits_mask |= lit_lanes;
+                            match_mask |= 1ull << j;
+                            op += 3u + lit;
+                        } else {
+                            const uint32_t nle = ext_len_bytes(lit);
+                            const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u;
+                            if (seq_end > dst_len) { failed = true; break; }
+                            const uint32_t offset = A + j - rdlane(old, j);
+                            if (lane == 0) dst[op] = (uint8_t)(0xF0u | mlen);
+                            write_ext_len(dst + op + 1u, lit, lane);
+                            uint8_t *o = dst + op + 1u + nle;
+                            if (lit_lanes & lane_bit) o[lane - a] = (uint8_t)fwd.x;
+                            if (lane < 2u) o[lit + lane] = (uint8_t)(offset >> (8u * lane));
+                            op = (uint32_t)seq_end;
+                        }
+                    } else if (js < 64u) {
+                        // ---- a lane whose slot may have been overwritten inside the window (or a long match) ----
+                        j = js;
+                        const uint64_t grp_j = (uint64_t)rdlane((uint32_t)grp, j) | ((uint64_t)rdlane((uint32_t)(grp >> 32), j) << 32);
+                        const uint64_t pm = grp_j & (ins | (((1ull << j) - 1ull) & rem));   // earlier put()s with this hash
+                        uint32_t m_cand, cy, cz, cw;
+                        bool ok;
+                        const uint32_t fx = rdlane(fwd.x, j);
+                        if (pm) {
+                            const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
+                            ok = rdlane(fwd.x, pr) == fx;                        // :348 (other tests hold in-window)
+                            m_cand = A + pr;
+                            cy = rdlane(fwd.y, pr); cz = rdlane(fwd.z, pr); cw = rdlane(fwd.w, pr);
+                        } else {
+                            ok = rdlane((uint32_t)vo, j) != 0;
+                            m_cand = rdlane(old, j);
+                            cy = rdlane(cold.y, j); cz = rdlane(cold.z, j); cw = rdlane(cold.w, j);
+                        }
+                        if (!ok) { skip |= 1ull << j; continue; }                 // probed, put, no match: next probe
+                        const uint32_t m_pos = A + j;
+                        const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ cz) << 32) | (rdlane(fwd.y, j) ^ cy);
+                        const uint32_t xb = rdlane(fwd.w, j) ^ cw;
+                        if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
+                        else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
+                        else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
+                        // immediate emission (:360-432), literals = low bytes of lanes a..j-1
+                        const uint32_t lit = j - a;
+                        const uint32_t offset = m_pos - m_cand;
+                        const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
+                        const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
+                        if (seq_end > dst_len) { failed = true; break; }
+                        if (lane == 0)
+                            dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (mlen >= 15u ? 15u : mlen));
+                        if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
+                        uint8_t *o = dst + op + 1u + nle;
+                        if (lane >= a && lane < j) o[lane - a] = (uint8_t)fwd.x;
+                        o += lit;
+                        if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));
+                        if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
+                        op = (uint32_t)seq_end;
+                    } else {
+                        if (f == 1u) {
+                            // no match in the whole window: the search goes on past it -> generic batches
+                            ins |= rem;
+                            continue_generic = true;
+                        }
+                        // else: restart a fresh window at the current anchor (its lanes >= f are re-probed there)
+                        break;
+                    }
+                    STAMP_COUNT(9);
+                    // ---- after the match (:435-442) ----
+                    ins |= ((2ull << j) - 1ull) & rem;                  // lanes f..j were probed and put
+                    const uint32_t e = j + kMinMatch + mlen;            // lane of the new anchor (may be >= 64)
+                    anchor = A + e;
+                    if (e >= 64u) break;                                // the next window inserts it as its lane 0
+                    ins |= 1ull << e;                                   // put(anchor) :438-441 (A + e < L here)
+                    a = e;
+                    f = e + 1u;
+                    skip = 0;
+                    if (f > 44u) break;                                 // few lanes left: start a fresh window
+                }
+                STAMP(4);
+                // ---- deferred emission of the simple sequences: 3 stores for the whole window ----
+                if (lits_mask & lane_bit) dst[v_base + lane] = (uint8_t)fwd.x;
+                if (match_mask & lane_bit) {
+                    dst[v_opk] = (uint8_t)((v_lit << 4) | mlo);
+                    const uint16_t off16 = (uint16_t)(pos - old);
+                    __builtin_memcpy(dst + v_opk + 1u + v_lit, &off16, 2);
+                }
+                STAMP(6);
+                if (failed) break;
+                // ---- leave the table as the serial loop would have ----
+                if (wr && !(ins & lane_bit)) table[h] = (T)old;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if ((ins & lane_bit) && (grp & ins & ~lanes_below & ~lane_bit) == 0) table[h] = (T)pos;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                STAMP(5);
+                if (!continue_generic) {
+                    if (anchor < L) { has_ins = true; F0 = anchor + 1u; }
+                    else { has_ins = false; F0 = L; }
+                    continue;
+                }
+                ub = 63;      // same search, next probe index: lane 0 of the next batch is position F0 + 63
+            }
+
+            // =====================================================================================
+            // Generic path: any acceleration, block tail, searches longer than one window.
+            // 64 probes of ONE search per step.
+            // =====================================================================================
             bool found = false, bailed = false;
             uint32_t m_pos = 0, m_cand = 0, m_local = 0;
             bool m_local_done = false;
@@ -205,32 +440,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
             if (bailed || !found) break;
 
             // ---------------- forward extension (:401-413) ----------------
-            uint32_t mlen = m_local;                                    // matchLength (without MINMATCH)
-            if (!m_local_done) {
-                const uint32_t ip0 = m_pos + kMinMatch, mt0 = m_cand + kMinMatch;
-                for (;;) {
-                    const uint32_t p = ip0 + mlen + lane * 16u;         // first byte this lane compares
-                    uint32_t n = 0;                                     // how many bytes it may compare
-                    if (p < match_limit) n = (match_limit - p) < 16u ? (match_limit - p) : 16u;
-                    uint32_t d = 0;                                     // equal bytes found
-                    if (n > 0) {
-                        const uint32_t q = mt0 + mlen + lane * 16u;
-                        if (p + 16u <= src_size) {
-                            d = first_diff16(ld128(src + p), ld128(src + q));
-                            if (d > n) d = n;
-                        } else {
-                            while (d < n && src[p + d] == src[q + d]) d++;
-                        }
-                    }
-                    const uint64_t stop = ballot(d < 16u);              // mismatch or limit inside this lane's chunk
-                    if (stop) {
-                        const uint32_t sl = first_lane(stop);
-                        mlen += sl * 16u + rdlane(d, sl);
-                        break;
-                    }
-                    mlen += 1024u;
-                }
-            }
+            const uint32_t mlen = m_local_done ? m_local
+                                               : extend_match(src, m_pos, m_cand, m_local, match_limit, src_size, lane);
 
             // ---------------- emit the sequence (:360-432) ----------------
             const uint32_t lit = m_pos - anchor;                        // :360
@@ -256,6 +467,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
         }
         res = failed ? kErrOutputTooSmall
                      : emit_last_literals(dst, dst_len, op, src + anchor, src_size - anchor, lane);   // :337, :446
+        STAMP(7);   // tail
+        STAMP_FLUSH;
     }
     if (lane == 0) d_result[blk] = res;
 }
@@ -267,11 +480,13 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
                                          const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks,
                                          uint32_t max_in_len, uint32_t acceleration) {
     if (nblocks == 0) return 0;
+    // experiment knob: extra dynamic LDS per workgroup lowers the number of resident waves per CU
+    static const uint32_t lds_pad = [] { const char *e = getenv("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
     // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
     if (max_in_len <= 65536u + 11u) {
         const uint32_t wpw = 4;   // 4 x 8 KiB = 32 KiB LDS per workgroup -> 5 workgroups (20 waves) per CU
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
-                           wpw * 4096 * sizeof(uint16_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
+                           wpw * 4096 * sizeof(uint16_t) + lds_pad, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
                            d_out_cap, d_result, nblocks, acceleration);
     } else {
         const uint32_t wpw = 2;   // 2 x 16 KiB = 32 KiB LDS per workgroup -> 5 workgroups (10 waves) per CU
@@ -281,3 +496,14 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
+
+#ifdef ZLZ4_STAMPS
+extern "C" int zlz4_debug_read_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_zlz4_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -7;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_zlz4_stamps), z, sizeof z) != hipSuccess) return -7;
+    }
+    return 0;
+}
+#endif
