@@ -85,6 +85,13 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `make` (hipcc --offload-arch=gfx950) -- "
                 "there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).
+        # If torch is going to be used in this process it must be loaded first, so that our library's
+        # DT_NEEDED libamdhip64.so.7 binds to the same runtime (device pointers / streams are shared).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)      # AttributeError if the library does not export it

@@ -16,6 +16,9 @@
 
 namespace zlz4 {
 
+// kWrite == false: size pass (no stores) -- used by the frame decoder to learn every block's
+// decompressed size before placing the blocks (lz4f.decompressFrame accumulates dstPos serially).
+template <bool kWrite>
 __global__ __launch_bounds__(256) void k_decompress_safe(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
@@ -64,10 +67,12 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
             if (lit > 0) {                                          // :134
                 if ((uint64_t)ip + lit > iend) { res = kErrCorrupted; break; }        // :136
                 if ((uint64_t)op + lit > oend) { res = kErrOutputTooSmall; break; }   // :137
-                if (lit <= 64u) {
+                if (!kWrite) {
+                    // size pass: literals are skipped, the window follows lazily
+                } else if (lit <= 64u) {
                     if (ip - wbase + lit > 64u) reload(ip);
                     const uint32_t j0 = ip - wbase;
-                    if (lane >= j0 && lane < j0 + lit) dst[op + (lane - j0)] = (uint8_t)w;
+                    if (kWrite && lane >= j0 && lane < j0 + lit) dst[op + (lane - j0)] = (uint8_t)w;
                 } else {
                     copy_bytes(dst + op, src + ip, lit, lane);      // :140
                 }
@@ -96,7 +101,9 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
             if (offset > op) { res = kErrCorrupted; break; }        // :181-186 (no dict) / :231
             const uint8_t *m = dst + (op - offset);
             uint8_t *o = dst + op;
-            if (offset >= ml || offset >= 1024u) {
+            if (!kWrite) {
+                // size pass: nothing to copy
+            } else if (offset >= ml || offset >= 1024u) {
                 // disjoint, or far enough apart that 1 KiB chunks in address order are exact (:244 / :238-240)
                 copy_bytes(o, m, ml, lane);
             } else if (offset >= 64u) {
@@ -124,7 +131,19 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
     if (nblocks == 0) return 0;
     const uint32_t waves_per_wg = 4;
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
-    hipLaunchKernelGGL(zlz4::k_decompress_safe, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
+    hipLaunchKernelGGL(zlz4::k_decompress_safe<true>, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
                        d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+    return hipGetLastError() == hipSuccess ? 0 : -7;
+}
+
+// size pass: d_out may be null; d_out_off / d_out_cap still give (dummy offset 0, capacity) per block
+extern "C" int zlz4_launch_decompress_sizes(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
+                                            const uint32_t *d_in_len, const uint64_t *d_out_off,
+                                            const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks) {
+    if (nblocks == 0) return 0;
+    const uint32_t waves_per_wg = 4;
+    const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
+    hipLaunchKernelGGL(zlz4::k_decompress_safe<false>, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
+                       d_in_len, (uint8_t *)nullptr, d_out_off, d_out_cap, d_result, nblocks);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
