@@ -1,0 +1,80 @@
+"""The C-ABI library loads and exports every symbol include/zlz4_amd.h declares (no compute calls: no GPU here)."""
+import os
+import re
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "zlz4_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zlz4f?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(zl):
+    L = zl.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(L, name), "libzlz4_amd.so does not export %s" % name
+    assert set(declared) == set(zl.SYMBOLS), "Python binding and header disagree"
+
+
+def test_library_is_hip_only(zl):
+    """The product must not link the oracle and must carry gfx950 code objects."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", zl.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out and "oracle" not in out
+    blob = open(zl.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"zo_compress" not in blob
+
+
+def test_pure_arithmetic_entry_points(zl, oracle):
+    for n in (0, 1, 12, 13, 255, 256, 65536, 4194304, 0x7E000000, 0x7E000001):
+        assert zl.compressBound(n) == oracle.compress_bound(n)                      # src/lz4.zig:80-83
+    assert zl.compressBound(65536) == 65809 and zl.compressBound(4194304) == 4210768
+    for bsid in (0, 4, 5, 6, 7):
+        for n in (0, 1, 65536, 65537, 10_000_000):
+            for bc in (0, 1):
+                for cc in (0, 1):
+                    p, q = zl.Prefs(), oracle.Prefs()
+                    for x in (p, q):
+                        x.block_size_id, x.block_checksum, x.content_checksum = bsid, bc, cc
+                    assert zl.lz4f.compressFrameBound(n, p) == oracle.compress_frame_bound(n, q)
+    frame = oracle.compress_frame(b"A" * 100)
+    assert zl.lz4f.headerSize(frame) == 7 == oracle.header_size(frame)
+    p = oracle.Prefs(); p.content_size = 100; p.dict_id = 5
+    assert zl.lz4f.headerSize(oracle.compress_frame(b"A" * 100, p)) == 19
+    assert zl.lz4f.headerSize(bytes([0x50, 0x2A, 0x4D, 0x18, 0, 0, 0, 0])) == 8      # skippable, lz4f.zig:459-462
+    for bad, name in ((b"abc", "FrameHeaderIncomplete"), (b"\0" * 8, "FrameTypeUnknown")):
+        try:
+            zl.lz4f.headerSize(bad)
+            assert False
+        except zl.Lz4Error as e:
+            assert e.name == name
+
+
+def test_error_names_follow_the_reference(zl):
+    names = {-1: "OutputTooSmall", -2: "InputTooLarge", -3: "CorruptedData", -4: "DecompressionFailed",
+             -5: "InvalidState", -6: "AllocationFailed", -101: "Generic", -111: "DstMaxSizeTooSmall",
+             -114: "FrameSizeWrong", -116: "DecompressionFailed", -117: "HeaderChecksumInvalid",
+             -118: "ContentChecksumInvalid", -107: "BlockChecksumInvalid"}
+    for code, name in names.items():
+        assert zl.error_name(code) == name
+    assert zl.lib().zlz4_version_string().startswith(b"zlz4-amd")
+
+
+def test_no_device_means_loud_failure(zl):
+    """On a box without a gfx950 GPU the compute entry points must fail (DeviceError), never fall back."""
+    if zl.device_available():
+        return
+    for fn, args in ((zl.compressDefault, (b"A" * 100,)), (zl.compressHC, (b"A" * 100, 9)),
+                     (zl.decompressSafe, (b"\x10A", 10)), (zl.lz4f.compressFrame, (b"A" * 100,)),
+                     (zl.lz4f.decompressFrame, (bytes.fromhex("04224d184040c000000000"), 10))):
+        try:
+            fn(*args)
+            assert False, "computed without a device"
+        except zl.Lz4Error as e:
+            assert e.name == "DeviceError"
