@@ -78,3 +78,18 @@ def test_no_device_means_loud_failure(zl):
             assert False, "computed without a device"
         except zl.Lz4Error as e:
             assert e.name == "DeviceError"
+
+
+def test_cpp_host_mirror_compiles_links_and_runs(zl, tmp_path):
+    """zig-lz4_amd/csrc/host/zlz4.hpp (the compiled-language mirror of src/root.zig) against the shared library."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("no g++")
+    exe = str(tmp_path / "hmc")
+    libdir = os.path.dirname(zl.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host_mirror_check.cpp"),
+                           "-L", libdir, "-lzlz4_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,61 @@
+// zlz4.hpp -- C++ host-side mirror of the reference's public facade (src/root.zig:1-57) over the C ABI.
+//
+// The reference is compiled Zig and no zig toolchain exists in the build image, so the compiled-language
+// host layer above the C ABI is this header (the Zig binding itself is zig/root.zig, delivered as source).
+// Same names and argument meaning as the reference; Zig error unions become zlz4::Result { value, error }.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../../include/zlz4_amd.h"
+
+namespace zlz4 {
+
+struct Result {
+    std::size_t value = 0;   // bytes written when ok()
+    std::int64_t error = 0;  // 0 or a ZLZ4_ERR_* / ZLZ4F_ERR_* code
+    bool ok() const { return error == 0; }
+    std::string error_name() const { return zlz4_error_name(error); }
+};
+inline Result wrap(std::int64_t r) { return r >= 0 ? Result{(std::size_t)r, 0} : Result{0, r}; }
+
+constexpr int MINMATCH = ZLZ4_MINMATCH;
+constexpr std::uint32_t LZ4_MAX_INPUT_SIZE = ZLZ4_MAX_INPUT_SIZE;
+constexpr std::uint32_t LZ4_DISTANCE_MAX = ZLZ4_DISTANCE_MAX;
+constexpr int LZ4HC_CLEVEL_MIN = ZLZ4HC_CLEVEL_MIN, LZ4HC_CLEVEL_DEFAULT = ZLZ4HC_CLEVEL_DEFAULT,
+              LZ4HC_CLEVEL_MAX = ZLZ4HC_CLEVEL_MAX;
+
+// lz4.compressBound, src/lz4.zig:80-83
+inline std::size_t compressBound(std::size_t n) { return zlz4_compress_bound(n); }
+// lz4.compressDefault, src/lz4.zig:283-285
+inline Result compressDefault(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap) {
+    return wrap(zlz4_compress_default(src, n, dst, cap));
+}
+// lz4.compressFast, src/lz4.zig:292-447
+inline Result compressFast(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap, std::uint32_t accel) {
+    return wrap(zlz4_compress_fast(src, n, dst, cap, accel));
+}
+// lz4.decompressSafe, src/lz4.zig:257-259
+inline Result decompressSafe(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap) {
+    return wrap(zlz4_decompress_safe(src, n, dst, cap));
+}
+// lz4hc.compressHC, src/lz4hc.zig:1440-1453
+inline Result compressHC(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap, std::int32_t level) {
+    return wrap(zlz4_compress_hc(src, n, dst, cap, level));
+}
+
+namespace lz4f {   // src/lz4f.zig
+using Preferences = zlz4f_prefs;
+constexpr std::uint32_t MAGICNUMBER = ZLZ4F_MAGICNUMBER;
+inline std::size_t compressFrameBound(std::size_t n, const Preferences *p = nullptr) { return zlz4f_compress_frame_bound(n, p); }
+inline Result compressFrame(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap, const Preferences *p = nullptr) {
+    return wrap(zlz4f_compress_frame(src, n, dst, cap, p));
+}
+inline Result decompressFrame(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap) {
+    return wrap(zlz4f_decompress_frame(src, n, dst, cap));
+}
+inline Result headerSize(const std::uint8_t *src, std::size_t n) { return wrap(zlz4f_header_size(src, n)); }
+}  // namespace lz4f
+
+}  // namespace zlz4

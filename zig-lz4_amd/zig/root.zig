@@ -1,0 +1,149 @@
+//! Drop-in replacement for jedisct1/zig-lz4's `src/root.zig` (reference src/root.zig:1-57):
+//! same `pub` names, same slices-in / error-union-out signatures, but every hot-path call is
+//! forwarded to the MI355X library `libzlz4_amd.so` through its C ABI (include/zlz4_amd.h).
+//! Host code stays pure Zig; link with `-lzlz4_amd` (see INTEGRATION.md).
+//!
+//! NOTE: this file could not be compiled in the build container (no zig toolchain); it is the
+//! binding a maintainer adds, kept deliberately mechanical.
+
+const std = @import("std");
+
+// ---- C ABI (include/zlz4_amd.h) ----
+extern "c" fn zlz4_compress_bound(input_size: usize) usize;
+extern "c" fn zlz4_compress_default(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize) i64;
+extern "c" fn zlz4_compress_fast(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, acceleration: u32) i64;
+extern "c" fn zlz4_compress_hc(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, level: i32) i64;
+extern "c" fn zlz4_decompress_safe(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize) i64;
+
+pub const CPrefs = extern struct {
+    block_size_id: u32 = 0,
+    block_mode: u32 = 0,
+    content_checksum: u32 = 0,
+    block_checksum: u32 = 0,
+    content_size: u64 = 0,
+    dict_id: u32 = 0,
+    compression_level: i32 = 0,
+};
+extern "c" fn zlz4f_compress_frame_bound(src_size: usize, prefs: ?*const CPrefs) usize;
+extern "c" fn zlz4f_compress_frame(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, prefs: ?*const CPrefs) i64;
+extern "c" fn zlz4f_decompress_frame(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize) i64;
+extern "c" fn zlz4f_header_size(src: [*]const u8, src_len: usize) i64;
+
+// ---- constants (reference src/lz4.zig:12-25, src/lz4hc.zig:28-31) ----
+pub const MINMATCH = 4;
+pub const LZ4_MAX_INPUT_SIZE = 0x7E000000;
+pub const LZ4_DISTANCE_MAX = 65535;
+pub const LZ4HC_CLEVEL_MIN = 2;
+pub const LZ4HC_CLEVEL_DEFAULT = 9;
+pub const LZ4HC_CLEVEL_MAX = 12;
+
+/// reference src/lz4.zig:48-55 plus the two device-side additions
+pub const Error = error{
+    OutputTooSmall,
+    InputTooLarge,
+    CorruptedData,
+    DecompressionFailed,
+    InvalidState,
+    AllocationFailed,
+    DeviceError,
+    Unsupported,
+};
+
+fn mapBlock(code: i64) Error!usize {
+    if (code >= 0) return @intCast(code);
+    return switch (code) {
+        -1 => error.OutputTooSmall,
+        -2 => error.InputTooLarge,
+        -3 => error.CorruptedData,
+        -4 => error.DecompressionFailed,
+        -5 => error.InvalidState,
+        -6 => error.AllocationFailed,
+        -8 => error.Unsupported,
+        else => error.DeviceError,
+    };
+}
+
+pub fn compressBound(inputSize: usize) usize {
+    return zlz4_compress_bound(inputSize);
+}
+pub fn compressDefault(src: []const u8, dst: []u8) Error!usize {
+    return mapBlock(zlz4_compress_default(src.ptr, src.len, dst.ptr, dst.len));
+}
+pub fn compressFast(src: []const u8, dst: []u8, acceleration: u32) Error!usize {
+    return mapBlock(zlz4_compress_fast(src.ptr, src.len, dst.ptr, dst.len, acceleration));
+}
+pub fn decompressSafe(src: []const u8, dst: []u8) Error!usize {
+    return mapBlock(zlz4_decompress_safe(src.ptr, src.len, dst.ptr, dst.len));
+}
+pub fn compressHC(src: []const u8, dst: []u8, compressionLevel: i32) Error!usize {
+    return mapBlock(zlz4_compress_hc(src.ptr, src.len, dst.ptr, dst.len, compressionLevel));
+}
+
+/// Mirror of the `lz4f` namespace (reference src/lz4f.zig); enum/struct shapes as in :64-122.
+pub const lz4f = struct {
+    pub const MAGICNUMBER: u32 = 0x184D2204;
+    pub const BlockSizeID = enum(u3) { default = 0, max64KB = 4, max256KB = 5, max1MB = 6, max4MB = 7 };
+    pub const BlockMode = enum(u1) { linked = 0, independent = 1 };
+    pub const ContentChecksum = enum(u1) { disabled = 0, enabled = 1 };
+    pub const BlockChecksum = enum(u1) { disabled = 0, enabled = 1 };
+    pub const FrameInfo = struct {
+        blockSizeID: BlockSizeID = .default,
+        blockMode: BlockMode = .linked,
+        contentChecksumFlag: ContentChecksum = .disabled,
+        contentSize: u64 = 0,
+        dictID: u32 = 0,
+        blockChecksumFlag: BlockChecksum = .disabled,
+    };
+    pub const Preferences = struct {
+        frameInfo: FrameInfo = .{},
+        compressionLevel: i32 = 0,
+        autoFlush: bool = false,
+        favorDecSpeed: bool = false,
+    };
+    /// reference src/lz4f.zig:31-55 (only the members this path can produce) + device additions
+    pub const FrameError = error{
+        Generic, MaxBlockSizeInvalid, HeaderVersionWrong, BlockChecksumInvalid, ReservedFlagSet,
+        AllocationFailed, SrcSizeTooLarge, DstMaxSizeTooSmall, FrameHeaderIncomplete, FrameTypeUnknown,
+        FrameSizeWrong, DecompressionFailed, HeaderChecksumInvalid, ContentChecksumInvalid,
+        DeviceError, Unsupported,
+    };
+    fn mapFrame(code: i64) FrameError!usize {
+        if (code >= 0) return @intCast(code);
+        return switch (code) {
+            -101 => error.Generic, -102 => error.MaxBlockSizeInvalid, -106 => error.HeaderVersionWrong,
+            -107 => error.BlockChecksumInvalid, -108 => error.ReservedFlagSet, -109 => error.AllocationFailed,
+            -110 => error.SrcSizeTooLarge, -111 => error.DstMaxSizeTooSmall, -112 => error.FrameHeaderIncomplete,
+            -113 => error.FrameTypeUnknown, -114 => error.FrameSizeWrong, -116 => error.DecompressionFailed,
+            -117 => error.HeaderChecksumInvalid, -118 => error.ContentChecksumInvalid, -8 => error.Unsupported,
+            else => error.DeviceError,
+        };
+    }
+    fn toC(p: Preferences) CPrefs {
+        return .{
+            .block_size_id = @intFromEnum(p.frameInfo.blockSizeID),
+            .block_mode = @intFromEnum(p.frameInfo.blockMode),
+            .content_checksum = @intFromEnum(p.frameInfo.contentChecksumFlag),
+            .block_checksum = @intFromEnum(p.frameInfo.blockChecksumFlag),
+            .content_size = p.frameInfo.contentSize,
+            .dict_id = p.frameInfo.dictID,
+            .compression_level = p.compressionLevel,
+        };
+    }
+    pub fn compressFrameBound(srcSize: usize, prefs: ?Preferences) usize {
+        if (prefs) |p| { const c = toC(p); return zlz4f_compress_frame_bound(srcSize, &c); }
+        return zlz4f_compress_frame_bound(srcSize, null);
+    }
+    /// the allocator argument of the reference (unused there, src/lz4f.zig:443) is kept for source compatibility
+    pub fn compressFrame(allocator: std.mem.Allocator, src: []const u8, dst: []u8, prefs: ?Preferences) FrameError!usize {
+        _ = allocator;
+        if (prefs) |p| { const c = toC(p); return mapFrame(zlz4f_compress_frame(src.ptr, src.len, dst.ptr, dst.len, &c)); }
+        return mapFrame(zlz4f_compress_frame(src.ptr, src.len, dst.ptr, dst.len, null));
+    }
+    pub fn decompressFrame(allocator: std.mem.Allocator, src: []const u8, dst: []u8) FrameError!usize {
+        _ = allocator;
+        return mapFrame(zlz4f_decompress_frame(src.ptr, src.len, dst.ptr, dst.len));
+    }
+    pub fn headerSize(src: []const u8) FrameError!usize {
+        return mapFrame(zlz4f_header_size(src.ptr, src.len));
+    }
+};
