@@ -63,9 +63,9 @@ def make_device_blocks(dist, nblocks, block_size, dev, seed):
         t = torch.randint(0, 256, (nblocks, block_size), dtype=torch.uint8, device=dev, generator=gd)
         t[:, : block_size // 2] = ord("X")
         return t
-    assert dist == "text"
+    assert dist in ("text", "reptext")
     pool_blocks = min(nblocks, max(1, (32 << 20) // block_size))
-    pool = torch.from_numpy(dg.make_blocks("text", pool_blocks, block_size, seed=seed)).to(dev)
+    pool = torch.from_numpy(dg.make_blocks(dist, pool_blocks, block_size, seed=seed)).to(dev)
     out = torch.empty((nblocks, block_size), dtype=torch.uint8, device=dev)
     done, rep = 0, 0
     idx = pool.long()
@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--dist", default="text", choices=["text", "ramp", "mixed", "random", "zero"])
+    ap.add_argument("--dist", default="text", choices=["text", "reptext", "ramp", "mixed", "random", "zero"])
     ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-mib", type=int, default=0)

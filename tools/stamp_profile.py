@@ -43,3 +43,4 @@ print("dist %s  blocks %d  kernel %.2f ms  batches %d  sequences %d  (%.1f seq/b
 for i, n in enumerate(names):
     print("  %-32s %6.2f %%   %8.0f cycles/sequence" % (n, 100.0 * buf[i] / tot, buf[i] / max(1, buf[9])))
 print("  total wave-cycles/sequence %.0f" % (tot / max(1, buf[9])))
+print("  window sequences %d  slow matches %d  slow failed probes %d  generic-path sequences %d" % (buf[9], buf[10], buf[11], buf[12]))

@@ -33,12 +33,12 @@
 // Diagnostic build only (-DZLZ4_STAMPS): per-phase shader-cycle sums, see profiles/ notes.
 #ifdef ZLZ4_STAMPS
 __device__ unsigned long long g_zlz4_stamps[16];
-#define STAMP_DECL unsigned long long st_acc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #define STAMP(i) do { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); \
                       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now) :: "memory"); \
                       __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
 #define STAMP_COUNT(i) do { st_acc[i] += 1; } while (0)
-#define STAMP_FLUSH do { if (lane == 0) for (int st_k = 0; st_k < 10; st_k++) atomicAdd(&g_zlz4_stamps[st_k], st_acc[st_k]); } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int st_k = 0; st_k < 16; st_k++) atomicAdd(&g_zlz4_stamps[st_k], st_acc[st_k]); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -204,38 +204,58 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                                    : (x3 ? 8u + ((uint32_t)__builtin_ctz(x3) >> 3) : 12u));
                 }
                 const bool single = grp == lane_bit;
-                const uint64_t vind = ballot(vo && single && mlo < 12u);          // resolved by scalar code alone
-                const uint64_t slow = ballot(wr && (!single || (vo && mlo >= 12u)));   // need the exact per-lane step
+                const bool oldfast = vo && mlo < 12u;         // result against the pre-window value is complete in registers
+                const uint64_t wrmask = ballot(wr);
+                const uint64_t cfast = ballot(oldfast);                                       // usable if no in-window put precedes
+                const uint64_t slow = ballot(wr && ((!single && !oldfast) || (vo && mlo >= 12u)));   // exact step if reached
+                const uint64_t nsing = ballot(wr && !single);
+                // per lane i: J = first cfast lane >= i, S = first slow lane >= i (64 = none),
+                // E = lane of the new anchor if the search that starts at i ends with the match at J
+                uint32_t J, S;
+                {
+                    const uint64_t mj = cfast >> lane, ms = slow >> lane;
+                    J = mj ? lane + (uint32_t)__builtin_ctzll(mj) : 64u;
+                    S = ms ? lane + (uint32_t)__builtin_ctzll(ms) : 64u;
+                }
+                uint32_t v_end = lane + kMinMatch + mlo;                          // anchor lane after a match at this lane
+                const uint32_t E = shfl(v_end, J & 63u);
 
-                uint64_t ins = has_ins ? 1ull : 0ull;
-                uint32_t f = 1;          // lane where the current search starts
+                uint32_t f = 1;          // next lane to probe
                 uint32_t a = 0;          // lane of the current anchor
-                uint64_t skip = 0;       // slow lanes already probed (and failed) in the current search
-                uint64_t lits_mask = 0, match_mask = 0;      // deferred emission of the simple sequences
-                uint32_t v_base = 0, v_opk = 0, v_lit = 0;
+                uint32_t nseq = 0;
+                uint64_t match_mask = 0, emit_mask = 0;      // all match lanes / those emitted by the deferred stores
+                uint64_t covered = 0;                        // lanes strictly inside a match: never put() (Q6)
+                uint32_t v_opk = 0, v_lit = 0;
                 bool continue_generic = false;
                 for (;;) {
-                    const uint64_t rem = ~((1ull << f) - 1ull);                 // lanes >= f
-                    const uint64_t c_fast = vind & rem, c_slow = slow & rem & ~skip;
-                    const uint32_t jf = c_fast ? first_lane(c_fast) : 64u;
-                    const uint32_t js = c_slow ? first_lane(c_slow) : 64u;
-                    uint32_t j, mlen;
-                    if (jf < js) {
-                        // ---- first valid probe is a hash-unique lane: everything is already in registers ----
-                        j = jf;
-                        mlen = rdlane(mlo, j);
+                    uint32_t j = 64u, s = 64u;
+                    if (f < 64u) { j = rdlane(J, f); s = rdlane(S, f); }
+                    const uint32_t x = s < j ? s : j;        // next lane that can possibly match
+                    if (x >= 64u) {
+                        if (nseq == 0u) continue_generic = true;   // the search goes on past the window -> generic batches
+                        // else: restart a fresh window at the current anchor (its lanes > a are re-probed there)
+                        break;
+                    }
+                    // earlier put()s of this window with the same hash (only lanes of duplicate-hash groups can have one):
+                    // every lane below x that is not strictly inside a match has been put
+                    uint64_t pm = 0;
+                    if ((nsing >> x) & 1ull) {
+                        const uint64_t grp_x = (uint64_t)rdlane((uint32_t)grp, x) | ((uint64_t)rdlane((uint32_t)(grp >> 32), x) << 32);
+                        pm = grp_x & wrmask & ~covered & ((1ull << x) - 1ull);
+                    }
+                    uint32_t e;
+                    if (x == j && pm == 0) {
+                        // ---- the probe reads the pre-window value: everything is already in registers ----
                         const uint32_t lit = j - a;
-                        const uint64_t lit_lanes = ((1ull << j) - 1ull) & ~((1ull << a) - 1ull);
+                        e = rdlane(E, f);
                         if (lit < 15u) {
                             if (op + 3u + lit > dst_len) { failed = true; break; }
-                            const bool is_l = (lit_lanes & lane_bit) != 0, is_j = lane == j;
-                            v_base = is_l ? op + 1u - a : v_base;
-                            v_opk = is_j ? op : v_opk;
-                            v_lit = is_j ? lit : v_lit;
-                            lits_mask |= lit_lanes;
-                            match_mask |= 1ull << j;
+                            v_opk = wrlane(op, j, v_opk);
+                            v_lit = wrlane(lit, j, v_lit);
+                            emit_mask |= 1ull << j;
                             op += 3u + lit;
                         } else {
+                            const uint32_t mlen = e - j - kMinMatch;
                             const uint32_t nle = ext_len_bytes(lit);
                             const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u;
                             if (seq_end > dst_len) { failed = true; break; }
@@ -243,32 +263,31 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                             if (lane == 0) dst[op] = (uint8_t)(0xF0u | mlen);
                             write_ext_len(dst + op + 1u, lit, lane);
                             uint8_t *o = dst + op + 1u + nle;
-                            if (lit_lanes & lane_bit) o[lane - a] = (uint8_t)fwd.x;
+                            if (lane >= a && lane < j) o[lane - a] = (uint8_t)fwd.x;
                             if (lane < 2u) o[lit + lane] = (uint8_t)(offset >> (8u * lane));
                             op = (uint32_t)seq_end;
                         }
-                    } else if (js < 64u) {
-                        // ---- a lane whose slot may have been overwritten inside the window (or a long match) ----
-                        j = js;
-                        const uint64_t grp_j = (uint64_t)rdlane((uint32_t)grp, j) | ((uint64_t)rdlane((uint32_t)(grp >> 32), j) << 32);
-                        const uint64_t pm = grp_j & (ins | (((1ull << j) - 1ull) & rem));   // earlier put()s with this hash
+                    } else {
+                        // ---- exact step: the slot was overwritten inside the window (pm != 0), or a long match ----
                         uint32_t m_cand, cy, cz, cw;
                         bool ok;
-                        const uint32_t fx = rdlane(fwd.x, j);
                         if (pm) {
                             const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
-                            ok = rdlane(fwd.x, pr) == fx;                        // :348 (other tests hold in-window)
+                            ok = rdlane(fwd.x, pr) == rdlane(fwd.x, x);          // :348 (other tests hold in-window)
                             m_cand = A + pr;
                             cy = rdlane(fwd.y, pr); cz = rdlane(fwd.z, pr); cw = rdlane(fwd.w, pr);
                         } else {
-                            ok = rdlane((uint32_t)vo, j) != 0;
-                            m_cand = rdlane(old, j);
-                            cy = rdlane(cold.y, j); cz = rdlane(cold.z, j); cw = rdlane(cold.w, j);
+                            ok = rdlane((uint32_t)vo, x) != 0;
+                            m_cand = rdlane(old, x);
+                            cy = rdlane(cold.y, x); cz = rdlane(cold.z, x); cw = rdlane(cold.w, x);
                         }
-                        if (!ok) { skip |= 1ull << j; continue; }                 // probed, put, no match: next probe
+                        if (!ok) { STAMP_COUNT(11); f = x + 1u; continue; }      // probed, put, no match: next probe
+                        STAMP_COUNT(10);
+                        j = x;
                         const uint32_t m_pos = A + j;
                         const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ cz) << 32) | (rdlane(fwd.y, j) ^ cy);
                         const uint32_t xb = rdlane(fwd.w, j) ^ cw;
+                        uint32_t mlen;
                         if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
                         else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
                         else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
@@ -287,36 +306,47 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                         if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));
                         if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
                         op = (uint32_t)seq_end;
-                    } else {
-                        if (f == 1u) {
-                            // no match in the whole window: the search goes on past it -> generic batches
-                            ins |= rem;
-                            continue_generic = true;
-                        }
-                        // else: restart a fresh window at the current anchor (its lanes >= f are re-probed there)
-                        break;
+                        e = j + kMinMatch + mlen;
+                        v_end = wrlane(e, j, v_end);
                     }
                     STAMP_COUNT(9);
                     // ---- after the match (:435-442) ----
-                    ins |= ((2ull << j) - 1ull) & rem;                  // lanes f..j were probed and put
-                    const uint32_t e = j + kMinMatch + mlen;            // lane of the new anchor (may be >= 64)
+                    match_mask |= 1ull << j;
+                    nseq++;
+                    {
+                        const uint64_t upto_e = e >= 64u ? ~0ull : (1ull << e) - 1ull;
+                        covered |= upto_e & ~((2ull << j) - 1ull);          // lanes j+1 .. e-1
+                    }
                     anchor = A + e;
-                    if (e >= 64u) break;                                // the next window inserts it as its lane 0
-                    ins |= 1ull << e;                                   // put(anchor) :438-441 (A + e < L here)
                     a = e;
-                    f = e + 1u;
-                    skip = 0;
-                    if (f > 44u) break;                                 // few lanes left: start a fresh window
+                    if (e >= 64u) break;                                // the next window inserts it as its lane 0
+                    f = e + 1u;                                         // put(anchor) :438-441: lane e is not `covered`
+                    if (f > 48u) break;                                 // few lanes left: start a fresh window
                 }
                 STAMP(4);
+                // ---- which sequence every lane belongs to (vector, once per window) ----
+                const uint64_t mm_below = match_mask & lanes_below;
+                const bool has_prev = mm_below != 0;
+                const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mm_below) : 0u;   // previous match lane
+                // (the shuffle must run in ALL lanes: ds_bpermute returns 0 from source lanes that EXEC masks off)
+                const uint32_t pend_all = shfl(v_end, pj);
+                const uint32_t pend = has_prev ? pend_all : 0u;              // its end = first lane of my literal run
+                const bool inside = (covered & lane_bit) != 0;               // strictly inside a match: never put()
+                const uint64_t mm_up = match_mask >> lane;
+                const uint32_t nj = mm_up ? lane + (uint32_t)__builtin_ctzll(mm_up) : 64u;        // my sequence's match lane
+                const uint32_t base = shfl(v_opk, nj & 63u);
                 // ---- deferred emission of the simple sequences: 3 stores for the whole window ----
-                if (lits_mask & lane_bit) dst[v_base + lane] = (uint8_t)fwd.x;
-                if (match_mask & lane_bit) {
+                if (nj < 64u && lane < nj && !inside && ((emit_mask >> (nj & 63u)) & 1ull))
+                    dst[base + 1u + (lane - pend)] = (uint8_t)fwd.x;
+                if (emit_mask & lane_bit) {
                     dst[v_opk] = (uint8_t)((v_lit << 4) | mlo);
                     const uint16_t off16 = (uint16_t)(pos - old);
                     __builtin_memcpy(dst + v_opk + 1u + v_lit, &off16, 2);
                 }
                 STAMP(6);
+                // lanes the serial loop put(): below the frontier and not strictly inside a match
+                const uint32_t f_end = continue_generic ? 64u : (a >= 64u ? 64u : a + 1u);
+                const uint64_t ins = wrmask & ~covered & (f_end >= 64u ? ~0ull : (1ull << f_end) - 1ull);
                 if (failed) break;
                 // ---- leave the table as the serial loop would have ----
                 if (wr && !(ins & lane_bit)) table[h] = (T)old;
@@ -438,6 +468,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 ub += 64;
             }
             if (bailed || !found) break;
+            STAMP_COUNT(12);
 
             // ---------------- forward extension (:401-413) ----------------
             const uint32_t mlen = m_local_done ? m_local

@@ -50,6 +50,41 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
 
         for (;;) {
             if (ip >= iend) break;                                  // :113
+            // ---- fast path: the whole sequence header (token, <= 14 literals, offset) sits inside the window,
+            //      no length extension bytes.  Same checks in the same order as the general path below,
+            //      written with 32-bit "remaining" arithmetic (ip <= iend and op <= oend always hold). ----
+            if (ip - wbase > 44u) reload(ip);                       // keep >= 20 window bytes ahead of the token
+            {
+                const uint32_t i0 = ip - wbase;
+                const uint32_t token = rdlane(w, i0);               // :116
+                const uint32_t lit = token >> 4, mlc = token & 15u; // :120, :157
+                const uint32_t in_rem = iend - ip - 1u;             // bytes after the token
+                if (lit != 15u && mlc != 15u && in_rem >= lit + 2u) {
+                    // (in_rem >= lit + 2 : literals fit (:136) and the offset is present (:146, :149))
+                    if (lit > oend - op) { res = kErrOutputTooSmall; break; }            // :137
+                    if (kWrite && lane > i0 && lane <= i0 + lit) dst[op + (lane - i0 - 1u)] = (uint8_t)w;   // :140
+                    op += lit;
+                    const uint32_t offset = rdlane(w, i0 + 1u + lit) | (rdlane(w, i0 + 2u + lit) << 8);   // :150
+                    ip += 3u + lit;
+                    if (offset == 0) { res = kErrCorrupted; break; }                     // :154
+                    const uint32_t ml = mlc + kMinMatch;                                 // :171 (4..18)
+                    if (ml > oend - op) { res = kErrOutputTooSmall; break; }             // :174
+                    if (offset > op) { res = kErrCorrupted; break; }                     // :181-186 / :231
+                    if (kWrite) {
+                        const uint8_t *m = dst + (op - offset);
+                        // out[op+k] = out[op-offset + (k mod offset)]; ml <= 18 lanes, one load + one store
+                        uint32_t k = lane;
+                        if (offset < ml) {                           // overlap (:235-241): k mod offset, k < 18
+                            if (offset == 1u) k = 0;
+                            else { while (k >= offset) k -= offset; }
+                        }
+                        if (lane < ml) dst[op + lane] = m[k];
+                    }
+                    op += ml;
+                    continue;
+                }
+            }
+            // ---- general path (length extensions, long literal runs, end of block, malformed input) ----
             const uint32_t token = fetch(ip);                       // :116
             ip += 1;
             uint32_t lit = token >> 4;                              // :120
@@ -60,19 +95,20 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     const uint32_t s = fetch(ip);
                     ip += 1;
                     lit += s;
+                    if (lit > 0xFFFF0000u) lit = 0xFFFF0000u;       // saturate: already larger than any input
                     if (s != 255u) break;
                 }
                 if (bad) { res = kErrCorrupted; break; }
             }
             if (lit > 0) {                                          // :134
-                if ((uint64_t)ip + lit > iend) { res = kErrCorrupted; break; }        // :136
-                if ((uint64_t)op + lit > oend) { res = kErrOutputTooSmall; break; }   // :137
+                if (lit > iend - ip) { res = kErrCorrupted; break; }        // :136
+                if (lit > oend - op) { res = kErrOutputTooSmall; break; }   // :137
                 if (!kWrite) {
                     // size pass: literals are skipped, the window follows lazily
                 } else if (lit <= 64u) {
                     if (ip - wbase + lit > 64u) reload(ip);
                     const uint32_t j0 = ip - wbase;
-                    if (kWrite && lane >= j0 && lane < j0 + lit) dst[op + (lane - j0)] = (uint8_t)w;
+                    if (lane >= j0 && lane < j0 + lit) dst[op + (lane - j0)] = (uint8_t)w;
                 } else {
                     copy_bytes(dst + op, src + ip, lit, lane);      // :140
                 }
@@ -80,7 +116,7 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 op += lit;
             }
             if (ip >= iend) break;                                  // :146
-            if (ip + 2u > iend) { res = kErrCorrupted; break; }     // :149
+            if (iend - ip < 2u) { res = kErrCorrupted; break; }     // :149
             const uint32_t offset = fetch(ip) | (fetch(ip + 1u) << 8);   // :150
             ip += 2;
             if (offset == 0) { res = kErrCorrupted; break; }        // :154
@@ -92,12 +128,13 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     const uint32_t s = fetch(ip);
                     ip += 1;
                     ml += s;
+                    if (ml > 0xFFFF0000u) ml = 0xFFFF0000u;         // saturate: can only end in OutputTooSmall / Corrupted
                     if (s != 255u) break;
                 }
                 if (bad) { res = kErrCorrupted; break; }
             }
             ml += kMinMatch;                                        // :171
-            if ((uint64_t)op + ml > oend) { res = kErrOutputTooSmall; break; }   // :174
+            if (ml > oend - op) { res = kErrOutputTooSmall; break; }   // :174
             if (offset > op) { res = kErrCorrupted; break; }        // :181-186 (no dict) / :231
             const uint8_t *m = dst + (op - offset);
             uint8_t *o = dst + op;

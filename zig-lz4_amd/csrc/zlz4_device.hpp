@@ -27,8 +27,14 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_re
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ uint32_t first_lane(uint64_t m) { return (uint32_t)__ffsll((long long)m) - 1u; }  // m != 0
+// NOTE: call it from wave-uniform control flow only -- ds_bpermute reads 0 from lanes that are masked off.
 __device__ __forceinline__ uint32_t shfl(uint32_t v, uint32_t src_lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+
+// write the wave-uniform `val` into lane `l` (uniform) of `old` (v_cmp + v_cndmask; VALU has headroom here)
+__device__ __forceinline__ uint32_t wrlane(uint32_t val, uint32_t l, uint32_t old) {
+    return (__lane_id() == l) ? val : old;
 }
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
