@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X LZ4 block codec on BASELINE.json's configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4] [--dist text|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5] [--dist text|...]
 
 Default workload = BASELINE.json configs[1]: 65 536 independent 64 KiB blocks (4 GiB),
 compressDefault, then decompressSafe of the result (the metric is "block
@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--dist", default="text", choices=["text", "reptext", "ramp", "mixed", "random", "zero"])
     ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -159,8 +159,8 @@ def main():
     if not zl.device_available():
         raise SystemExit("libzlz4_amd.so: no usable gfx950 device")
 
-    block = 65536
-    defaults = {"cfg2": 65536, "cfg3": 1 << 20, "cfg4": 16384}
+    defaults = {"cfg2": 65536, "cfg3": 1 << 20, "cfg4": 16384, "cfg5": 1024}
+    block = (4 << 20) if args.workload == "cfg5" else 65536
     nblocks = args.blocks or defaults[args.workload]
     hc_level = 9 if args.workload == "cfg4" else None
     slot = (zl.compressBound(block) + 15) // 16 * 16          # 65 809 -> 65 824
@@ -168,55 +168,132 @@ def main():
         "cfg2": "configs[1]: %d x 64 KiB blocks, compressDefault then decompressSafe (round trip), D-%s",
         "cfg3": "configs[2]: decompressSafe only, %d pre-compressed 64 KiB blocks, D-%s",
         "cfg4": "configs[3]: compressHC level 9 then decompressSafe, %d x 64 KiB blocks, D-%s",
+        "cfg5": "configs[4]: lz4f frame, %d independent 4 MiB blocks per GPU, compressFrame then decompressFrame, D-%s",
     }
     workload = names[args.workload] % (nblocks, args.dist)
-
-    t0 = time.time()
-    inp = make_device_blocks(args.dist, nblocks, block, dev, seed=rank + 1)
-    torch.cuda.synchronize()
-    log("[rank %d] generated %.2f GiB of D-%s in %.1f s" % (rank, nblocks * block / GIB, args.dist, time.time() - t0))
-
-    ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
-    in_off = ar * block
-    in_len = torch.full((nblocks,), block, dtype=torch.int32, device=dev)
-    slot_off = ar * slot
-    slot_cap = torch.full((nblocks,), slot, dtype=torch.int32, device=dev)
-    comp = torch.empty(nblocks * slot, dtype=torch.uint8, device=dev)
-    csize = torch.empty(nblocks, dtype=torch.int64, device=dev)
-    out = torch.empty((nblocks, block), dtype=torch.uint8, device=dev)
-    dsize = torch.empty(nblocks, dtype=torch.int64, device=dev)
-    ws = None
-    if hc_level is not None:
-        ws = torch.empty(zl.batch_compress_hc_workspace(nblocks, block), dtype=torch.uint8, device=dev)
-
-    def do_compress():
-        if hc_level is None:
-            zl.batch_compress_fast(inp, in_off, in_len, comp, slot_off, slot_cap, csize, block, 1)
-        else:
-            zl.batch_compress_hc(inp, in_off, in_len, comp, slot_off, slot_cap, csize, block, hc_level, ws)
-
-    clen32 = None
-
-    def do_decompress():
-        zl.batch_decompress_safe(comp, slot_off, clen32, out, in_off, in_len, dsize)
-
-    # untimed first pass: produces the compressed batch and checks the round trip
-    do_compress()
-    torch.cuda.synchronize()
-    assert int(csize.min()) > 0, "compress reported an error: %d" % int(csize.min())
-    clen32 = csize.to(torch.int32)
-    do_decompress()
-    torch.cuda.synchronize()
-    assert bool((dsize == block).all()), "decompress size mismatch"
-    assert torch.equal(out, inp), "round trip mismatch"
-    total_c = int(csize.sum())
     total_n = nblocks * block
+    decomp_only = args.workload == "cfg3"
+    frame_mode = args.workload == "cfg5"
+
+    if frame_mode:
+        # ---- config 5: one frame per GPU shard, device-resident source and destination ----
+        t0 = time.time()
+        inp = make_device_blocks(args.dist, nblocks, block, dev, seed=rank + 1).reshape(-1)
+        torch.cuda.synchronize()
+        log("[rank %d] generated %.2f GiB of D-%s in %.1f s" % (rank, total_n / GIB, args.dist, time.time() - t0))
+        prefs = zl.Prefs()
+        prefs.block_size_id = 7          # max4MB
+        prefs.block_mode = 1             # independent
+        bound = zl.lz4f.compressFrameBound(total_n, prefs)
+        frame = torch.empty(bound, dtype=torch.uint8, device=dev)
+        out = torch.empty(total_n, dtype=torch.uint8, device=dev)
+        L = zl.lib()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        fsize = [0]
+
+        def do_compress():
+            r = L.zlz4f_compress_frame_device(st, C.c_void_p(inp.data_ptr()), total_n, C.c_void_p(frame.data_ptr()),
+                                              bound, C.byref(prefs))
+            assert r > 0, "compressFrame failed: %s" % zl.error_name(r)
+            fsize[0] = r
+
+        def do_decompress():
+            r = L.zlz4f_decompress_frame_device(st, C.c_void_p(frame.data_ptr()), fsize[0], C.c_void_p(out.data_ptr()),
+                                                total_n)
+            assert r == total_n, "decompressFrame failed: %s" % zl.error_name(r)
+
+        do_compress()
+        do_decompress()
+        torch.cuda.synchronize()
+        assert torch.equal(out, inp), "frame round trip mismatch"
+        total_c = fsize[0]
+        sample_src = inp.reshape(nblocks, block)
+        csize_head = None
+    elif decomp_only:
+        # ---- config 3: compress chunk by chunk (untimed), keep only the compressed slots, time decompression ----
+        chunk = min(nblocks, 65536)
+        comp = torch.empty(nblocks * slot, dtype=torch.uint8, device=dev)
+        csize = torch.empty(nblocks, dtype=torch.int64, device=dev)
+        ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
+        in_off = ar * block
+        in_len = torch.full((nblocks,), block, dtype=torch.int32, device=dev)
+        slot_off = ar * slot
+        slot_cap = torch.full((nblocks,), slot, dtype=torch.int32, device=dev)
+        t0 = time.time()
+        for c0 in range(0, nblocks, chunk):
+            n = min(chunk, nblocks - c0)
+            part = make_device_blocks(args.dist, n, block, dev, seed=(rank + 1) * 1000 + c0 // chunk)
+            zl.batch_compress_fast(part, in_off[:n], in_len[:n], comp[c0 * slot:], slot_off[:n], slot_cap[:n],
+                                   csize[c0:c0 + n], block, 1)
+            torch.cuda.synchronize()
+            del part
+        log("[rank %d] pre-compressed %.1f GiB in %.1f s" % (rank, total_n / GIB, time.time() - t0))
+        assert int(csize.min()) > 0
+        clen32 = csize.to(torch.int32)
+        out = torch.empty((nblocks, block), dtype=torch.uint8, device=dev)
+        dsize = torch.empty(nblocks, dtype=torch.int64, device=dev)
+
+        def do_compress():
+            pass
+
+        def do_decompress():
+            zl.batch_decompress_safe(comp, slot_off, clen32, out, in_off, in_len, dsize)
+
+        do_decompress()
+        torch.cuda.synchronize()
+        assert bool((dsize == block).all()), "decompress size mismatch"
+        for c0 in range(0, nblocks, chunk):      # regenerate each chunk and compare
+            n = min(chunk, nblocks - c0)
+            part = make_device_blocks(args.dist, n, block, dev, seed=(rank + 1) * 1000 + c0 // chunk)
+            assert torch.equal(out[c0:c0 + n], part), "round trip mismatch in chunk %d" % (c0 // chunk)
+            sample_src = part if c0 == 0 else sample_src
+        total_c = int(csize.sum())
+        csize_head = [int(x) for x in csize[:4].cpu()]
+    else:
+        # ---- configs 2 and 4: compress then decompress the same resident batch ----
+        t0 = time.time()
+        inp = make_device_blocks(args.dist, nblocks, block, dev, seed=rank + 1)
+        torch.cuda.synchronize()
+        log("[rank %d] generated %.2f GiB of D-%s in %.1f s" % (rank, total_n / GIB, args.dist, time.time() - t0))
+        ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
+        in_off = ar * block
+        in_len = torch.full((nblocks,), block, dtype=torch.int32, device=dev)
+        slot_off = ar * slot
+        slot_cap = torch.full((nblocks,), slot, dtype=torch.int32, device=dev)
+        comp = torch.empty(nblocks * slot, dtype=torch.uint8, device=dev)
+        csize = torch.empty(nblocks, dtype=torch.int64, device=dev)
+        out = torch.empty((nblocks, block), dtype=torch.uint8, device=dev)
+        dsize = torch.empty(nblocks, dtype=torch.int64, device=dev)
+        ws = None
+        if hc_level is not None:
+            ws = torch.empty(zl.batch_compress_hc_workspace(nblocks, block), dtype=torch.uint8, device=dev)
+        clen = [None]
+
+        def do_compress():
+            if hc_level is None:
+                zl.batch_compress_fast(inp, in_off, in_len, comp, slot_off, slot_cap, csize, block, 1)
+            else:
+                zl.batch_compress_hc(inp, in_off, in_len, comp, slot_off, slot_cap, csize, block, hc_level, ws)
+
+        def do_decompress():
+            zl.batch_decompress_safe(comp, slot_off, clen[0], out, in_off, in_len, dsize)
+
+        # untimed first pass: produces the compressed batch and checks the round trip
+        do_compress()
+        torch.cuda.synchronize()
+        assert int(csize.min()) > 0, "compress reported an error: %d" % int(csize.min())
+        clen[0] = csize.to(torch.int32)
+        do_decompress()
+        torch.cuda.synchronize()
+        assert bool((dsize == block).all()), "decompress size mismatch"
+        assert torch.equal(out, inp), "round trip mismatch"
+        total_c = int(csize.sum())
+        sample_src = inp
+        csize_head = [int(x) for x in csize[:4].cpu()]
     log("[rank %d] round trip ok, ratio %.3f" % (rank, total_n / total_c))
 
-    decomp_only = args.workload == "cfg3"
     for _ in range(args.warmup):
-        if not decomp_only:
-            do_compress()
+        do_compress()
         do_decompress()
     torch.cuda.synchronize()
     if dist_on:
@@ -226,8 +303,7 @@ def main():
     t_start = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        if not decomp_only:
-            do_compress()
+        do_compress()
         ev[k][1].record()
         do_decompress()
         ev[k][2].record()
@@ -246,11 +322,22 @@ def main():
         value = world * total_n * args.steps / elapsed / GIB
         comp_gibs = None if decomp_only else total_n / (tc_ms * 1e-3) / GIB
         dec_gibs = total_n / (td_ms * 1e-3) / GIB
+        kc = {"cfg2": "zlz4::k_compress_fast<uint16_t>", "cfg4": "zlz4::k_hc_search<uint16_t,uint32_t>",
+              "cfg5": "zlz4::k_compress_fast<uint32_t>", "cfg3": None}[args.workload]
         if decomp_only:
-            dom, dom_ms = "zlz4::k_decompress_safe", td_ms
+            dom, dom_ms = "zlz4::k_decompress_safe<true>", td_ms
         else:
-            dom, dom_ms = ("zlz4::k_compress_fast<uint16_t>" if hc_level is None else "zlz4::k_hc_search"), tc_ms
-        achieved = (total_n + total_c) / (dom_ms * 1e-3) / 1e9
+            dom, dom_ms = kc, tc_ms
+        # HBM traffic from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE collected in separate
+        # runs, tools/pmc_run.sh); bytes per launch, null when no profile of this workload/distribution is committed
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj.get("%s/%s/%d" % (args.workload, args.dist, nblocks), {})
+        except Exception:
+            pass
+        algo = total_n + total_c
+        achieved = algo / (dom_ms * 1e-3) / 1e9
         res = {
             "metric": "GiB/s uncompressed, block compress+decompress",
             "value": value, "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -263,20 +350,26 @@ def main():
             "compress_gibs_per_gpu": comp_gibs, "decompress_gibs_per_gpu": dec_gibs,
             "compress_ms": None if decomp_only else tc_ms, "decompress_ms": td_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": total_n + total_c, "avg_launch_ms": dom_ms},
-            "roofline_decompress": {"bound": "hbm", "kernel": "zlz4::k_decompress_safe",
-                                    "achieved": (total_n + total_c) / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": (total_n + total_c) / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "traffic": None, "avg_launch_ms": td_ms},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic.get("decompress" if decomp_only else "compress"),
+                         "traffic_source": traffic.get("source"),
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms},
+            "roofline_decompress": {"bound": "hbm", "kernel": "zlz4::k_decompress_safe<true>",
+                                    "achieved": algo / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": algo / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "traffic": traffic.get("decompress"), "avg_launch_ms": td_ms},
         }
+        if frame_mode:
+            res["roofline"]["note"] = ("frame calls = descriptor + batch compress + plan + scatter kernels plus "
+                                       "hipMalloc/hipFree of the slot arena inside the call; avg_launch_ms is the whole call")
         if world == 1 and not args.no_cpu:
             mib = args.cpu_sample_mib or (1024 if hc_level is None else 96)
             nsamp = max(1, min(nblocks, mib * (1 << 20) // block))
-            sample = inp[:nsamp].cpu().numpy()
+            sample = sample_src[:nsamp].cpu().numpy()
             cb = cpu_baseline(sample, block, slot, hc_level)
             # the same sample through the HIP path must give the same compressed sizes
-            assert cb["compressed_sizes_head"] == [int(x) for x in csize[:4].cpu()], "HIP vs oracle size mismatch"
+            if csize_head is not None:
+                assert cb["compressed_sizes_head"] == csize_head[:len(cb["compressed_sizes_head"])], "HIP vs oracle size mismatch"
             res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     if dist_on:

@@ -24,6 +24,8 @@
 //                    results, encodeSequence with its limitedOutput checks, final literals.
 // K2 does redundant work for positions inside matches, but it has 64K-way parallelism per
 // block where the reference has none.
+#include <cstdlib>
+
 #include "zlz4_device.hpp"
 
 namespace zlz4 {
@@ -140,16 +142,9 @@ __device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, ui
     return c;
 }
 
-// One search = walk of the hash chain of position p (:571-622) + optional pattern analysis (:626-678).
-// Chain lengths differ wildly between neighbouring positions, so a wave does not own 64 fixed positions:
-// it owns a RANGE of positions and every lane pulls the next unsearched one as soon as its own search
-// ends.  Each loop iteration tests ONE candidate per busy lane with ONE memory round trip: the lane keeps
-// the 16 bytes at p in registers, loads 16 bytes at the candidate plus the candidate's chain link, and gets
-// the first 16 bytes of lz4Count (:234-264) from a single compare; only longer matches take extra
-// 16-byte COUNT steps.
-constexpr uint32_t kHcRange = 512;     // positions per wave
-constexpr uint32_t kNone = 0xFFFFFFFFu;
-
+// One lane per position, each lane runs its own chain walk.  (A per-wave work-queue variant that re-assigns
+// finished lanes and tests one candidate per loop iteration with 16-byte compares was measured 15-40 % SLOWER
+// on MI355X: this kernel is bound by gather throughput, not by divergence -- see DESIGN.md section 6.)
 template <typename T, typename R>   // R = packed result: u32 (len | off << 16) for T = u16, u64 (len | off << 32) otherwise
 __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d_in,
                                                     const uint64_t *__restrict__ d_in_off,
@@ -159,148 +154,71 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
                                                     int32_t max_attempts) {
     const uint32_t b = blockIdx.y;
     if (b >= nblocks) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n = rfl(d_in_len[blk0 + b]);
+    const uint32_t n = d_in_len[blk0 + b];
     const uint32_t np = n_positions(n);
-    const uint32_t wave = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const uint32_t p0 = wave * kHcRange;
-    if (p0 >= np) return;
-    const uint32_t p1 = p0 + kHcRange < np ? p0 + kHcRange : np;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
     const uint8_t *src = d_in + d_in_off[blk0 + b];
     const T *link = d_link + (uint64_t)b * link_stride;
-    R *res = d_res + (uint64_t)b * link_stride;
     const uint32_t limit = n - kLastLiterals;                    // iHighLimit = matchlimit :989, :1011
     const bool pattern_analysis = max_attempts > 128;            // :983
-    const uint64_t lanes_below = (1ull << lane) - 1ull;
 
-    // per-lane search state
-    uint32_t p = kNone, m = 0, best_off = 0, cnt = 0;
-    T lk = 0;                                                    // link[m] of the candidate being tested
-    u32x4 p16 = {0, 0, 0, 0};                                    // src[p .. p+16)
-    int32_t nb = 0, best_len = 0;
-    bool counting = false;
-    uint32_t next = p0;                                          // wave-uniform: next unassigned position
-
-    for (;;) {
-        // ---- idle lanes take the next positions of the range ----
-        const uint64_t idle = ballot(p == kNone);
-        if (idle && next < p1) {
-            const uint32_t mine = next + (uint32_t)__popcll(idle & lanes_below);
-            if (p == kNone && mine < p1) {
-                p = mine;
-                // insertAndGetWiderMatch with iLowLimit == ip, longest = MINMATCH-1 (:522-534)
-                if (p + 16u <= n) p16 = ld128(src + p);
-                else { p16.x = ld32(src + p); p16.y = p16.z = p16.w = 0; }        // :558 (the last <= 4 positions of a block)
-                best_len = (int32_t)kMinMatch - 1;               // :560
-                best_off = 0;
-                m = Links<T>::first(p, link[p]);                 // :563  hashTable[hashPtr(ip)]
-                nb = max_attempts;
-                counting = false;
-                if (m == 0) {                                    // :566-568 empty slot: result = {3, 0}, no pattern analysis
-                    res[p] = sizeof(R) == 4 ? (R)3u : (R)3ull;
-                    p = kNone;
+    // insertAndGetWiderMatch with iLowLimit == ip, longest = MINMATCH-1 (:522-534)
+    const uint32_t lowest = p < 65536u ? 0u : p - kMaxDist;      // :553-554 (lowLimit == 0)
+    const uint32_t pattern = ld32(src + p);                      // :558
+    int32_t best_len = (int32_t)kMinMatch - 1;                   // :560
+    uint32_t best_off = 0;
+    uint32_t m = Links<T>::first(p, link[p]);                    // :563  hashTable[hashPtr(ip)]
+    if (m != 0) {                                                // :566-568
+        int32_t nb = max_attempts;
+        while (m > 0 && nb > 0) {                                // :571
+            if (m > p || (p - m) > kMaxDist) break;              // :573
+            nb -= 1;                                             // :577
+            if (m >= lowest) {                                   // :579
+                if (ld32(src + m) == pattern) {                  // :586
+                    const int32_t mlt = (int32_t)(kMinMatch + lz4_count(src, p + kMinMatch, m + kMinMatch, limit));
+                    // back == 0: `ip > iLowLimit` is false (:596)
+                    if (mlt > best_len) {                        // :607
+                        best_len = mlt;
+                        best_off = p - m;
+                        if (mlt > max_attempts) break;           // :613
+                    }
                 }
             }
-            next += (uint32_t)__popcll(idle);
+            const uint32_t delta = Links<T>::delta(m, link[m]);  // :619
+            if (delta == 0 || delta > m) break;                  // :620
+            m -= delta;                                          // :621
         }
-        if (ballot(p != kNone) == 0) {
-            if (next >= p1) break;     // range exhausted and nobody is searching
-            continue;                  // every newly assigned position had an empty slot: assign more
-        }
-        if (p == kNone) continue;     // (lanes rejoin at the loop head; the ballots above run in uniform flow)
-
-        // every busy lane now has a candidate m that passed `m > 0 && nb > 0` (:571); :573 is tested first
-        bool finished = false, cand_done = false;
-        const bool wide = p + 16u <= n;                          // 16-byte compares stay inside the block (m < p)
-        if (!counting && (p - m) > kMaxDist) {
-            finished = true;                                     // :573 (m > p cannot happen: links point backwards)
-        } else if (!counting) {
-            // ---- WALK: test candidate m (:577-592); its chain link is fetched in the same round trip ----
-            lk = link[m];
-            nb -= 1;                                             // :577;  m >= lowestMatchIndex (:579) follows from :573
-            if (wide) {
-                const u32x4 c16 = ld128(src + m);
-                const uint32_t d = first_diff16(p16, c16);       // equal leading bytes, 0..16
-                if (d >= kMinMatch) {                            // :586
-                    const uint32_t avail = limit - p;            // lz4Count stops at iHighLimit
-                    if (d == 16u && avail > 16u) { counting = true; cnt = 12; }
-                    else { cnt = (d < avail ? d : avail) - kMinMatch; cand_done = true; }
-                }
-            } else if (ld32(src + m) == p16.x) {
-                uint32_t k = 0;                                  // byte-wise lz4Count for the block's last positions
-                while (p + kMinMatch + k < limit && src[p + kMinMatch + k] == src[m + kMinMatch + k]) k++;
-                cnt = k;
-                cand_done = true;
-            }
-        } else {
-            // ---- COUNT: continue lz4Count, 16 bytes per step ----
-            const uint32_t a = p + kMinMatch + cnt, c = m + kMinMatch + cnt;
-            if (a + 16u <= n) {
-                const uint32_t d = first_diff16(ld128(src + a), ld128(src + c));
-                const uint32_t room = limit - a;                 // > 0 while counting
-                if (d < 16u || room <= 16u) { cnt += d < room ? d : room; cand_done = true; }
-                else cnt += 16;
-            } else {
-                uint32_t k = 0;
-                while (a + k < limit && src[a + k] == src[c + k]) k++;
-                cnt += k;
-                cand_done = true;
-            }
-        }
-        if (cand_done) {
-            counting = false;
-            const int32_t mlt = (int32_t)(kMinMatch + cnt);      // back == 0: `ip > iLowLimit` is false (:596)
-            if (mlt > best_len) {                                // :607
-                best_len = mlt;
-                best_off = p - m;
-                if (mlt > max_attempts) finished = true;         // :613
-            }
-        }
-        if (!finished && !counting) {
-            // ---- follow the chain (:619-621), then the loop condition of the next round (:571) ----
-            const uint32_t delta = Links<T>::delta(m, lk);
-            if (delta == 0 || delta > m) finished = true;        // :620
-            else {
-                m -= delta;                                      // :621
-                if (!(m > 0 && nb > 0)) finished = true;         // :571
-            }
-        }
-        if (finished) {
-            const uint32_t pattern = p16.x;
-            if (pattern_analysis && best_len > 0 &&              // :626
-                ((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {   // :631
-                const uint32_t lowest = p < 65536u ? 0u : p - kMaxDist;      // :553-554 (lowLimit == 0)
-                const uint32_t delta = Links<T>::delta(m, link[m]);          // :627 (m == 0 -> link[0] -> delta 0)
-                if (delta == 1) {                                            // :629
-                    const uint32_t src_pat_len = count_pattern(src, p + 4u, limit, pattern) + 4u;   // :633
-                    const uint32_t cand = m - 1u;                // :636
-                    if (cand >= lowest) {                        // :637 (dictIdx == 0)
-                        if (ld32(src + cand) == pattern) {       // :644
-                            const uint32_t fwd_len = count_pattern(src, cand + 4u, limit, pattern) + 4u;   // :646
-                            const uint32_t back_len = reverse_count_pattern(src, cand, pattern);           // :650
-                            uint32_t lo = cand - back_len;       // :653
-                            if (lo < lowest) lo = lowest;
-                            const uint32_t lim_back = cand - lo;
-                            const uint32_t seg_len = lim_back + fwd_len;                                   // :654
-                            const int32_t max_ml = (int32_t)(seg_len < src_pat_len ? seg_len : src_pat_len);   // :658
-                            uint32_t new_m;
-                            if (seg_len >= src_pat_len && fwd_len <= src_pat_len) new_m = cand + fwd_len - src_pat_len;   // :660-662
-                            else new_m = cand - lim_back;        // :665
-                            if (max_ml > best_len && (p - new_m) <= kMaxDist) {   // :669
-                                best_len = max_ml;
-                                best_off = p - new_m;
-                            }
+        if (pattern_analysis && best_len > 0) {                  // :626
+            const uint32_t delta = Links<T>::delta(m, link[m]);  // :627 (m == 0 -> link[0] -> delta 0)
+            if (delta == 1 && ((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {   // :629-631
+                const uint32_t src_pat_len = count_pattern(src, p + 4u, limit, pattern) + 4u;   // :633
+                const uint32_t cand = m - 1u;                    // :636
+                if (cand >= lowest) {                            // :637 (dictIdx == 0)
+                    if (ld32(src + cand) == pattern) {           // :644
+                        const uint32_t fwd_len = count_pattern(src, cand + 4u, limit, pattern) + 4u;   // :646
+                        const uint32_t back_len = reverse_count_pattern(src, cand, pattern);           // :650
+                        uint32_t lo = cand - back_len;           // :653
+                        if (lo < lowest) lo = lowest;
+                        const uint32_t lim_back = cand - lo;
+                        const uint32_t seg_len = lim_back + fwd_len;                                   // :654
+                        const int32_t max_ml = (int32_t)(seg_len < src_pat_len ? seg_len : src_pat_len);   // :658
+                        uint32_t new_m;
+                        if (seg_len >= src_pat_len && fwd_len <= src_pat_len) new_m = cand + fwd_len - src_pat_len;   // :660-662
+                        else new_m = cand - lim_back;            // :665
+                        if (max_ml > best_len && (p - new_m) <= kMaxDist) {   // :669
+                            best_len = max_ml;
+                            best_off = p - new_m;
                         }
                     }
                 }
             }
-            R r;
-            if (sizeof(R) == 4) r = (R)((uint32_t)best_len | (best_off << 16));
-            else r = (R)((uint64_t)(uint32_t)best_len | ((uint64_t)best_off << 32));
-            res[p] = r;
-            p = kNone;
         }
     }
+    R r;
+    if (sizeof(R) == 4) r = (R)((uint32_t)best_len | (best_off << 16));
+    else r = (R)((uint64_t)(uint32_t)best_len | ((uint64_t)best_off << 32));
+    d_res[(uint64_t)b * link_stride + p] = r;
 }
 
 // ------------------------------------------------------------------ K3: greedy parse + emit
@@ -412,8 +330,8 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
                            d_in_len, d_link, stride, b0, nb);
-        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 4u * kHcRange - 1u) / (4u * kHcRange), nb), dim3(256), 0,
-                           stream, d_in, d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts);
+        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 255u) / 256u, nb), dim3(256), 0, stream, d_in, d_in_off,
+                           d_in_len, d_link, stride, d_res, b0, nb, max_attempts);
         hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
                            d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb);
     }
