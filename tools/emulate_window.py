@@ -75,62 +75,80 @@ def compress(src, accel=1, dst_len=None, RESTART=48, trace=False):
             Sx = [first_ge(slow, i) for i in range(64)]
             v_end = [i + 4 + mlo[i] for i in range(64)]
             E = [v_end[J[i] & 63] for i in range(64)]
-            f, a, nseq = 1, 0, 0
-            match_mask = emit_mask = covered = 0
-            v_opk = [0]*64; v_lit = [0]*64
+            f, a, nseq, covered = 1, 0, 0, 0
             continue_generic = False
+            tight = dst_len - op < 512
             while True:
-                j = s = 64
-                if f < 64: j, s = J[f], Sx[f]
-                x = s if s < j else j
+                # ---- fast run: collect match lanes with a minimal scalar loop ----
+                a0, op0, mm_run = a, op, 0
+                while f < 64 and (f < 49 or (nseq == 0 and mm_run == 0)):
+                    j, sl = J[f], Sx[f]
+                    if tight or sl <= j or j - a >= 15 or (nsing >> j) & 1: break
+                    mm_run |= 1 << j
+                    e = v_end[j]; a = e; f = e + 1
+                if mm_run:
+                    # ---- vector flush of the run ----
+                    jlast = msb(mm_run)
+                    litmask = 0; cov_run = 0
+                    info = []
+                    for i in range(64):
+                        mb = mm_run & ((1 << i) - 1)
+                        has_prev = mb != 0
+                        pend = v_end[msb(mb)] if has_prev else a0
+                        cov = has_prev and i < pend
+                        is_m = (mm_run >> i) & 1
+                        is_lit = i >= a0 and i < jlast and not cov and not is_m
+                        if is_lit: litmask |= 1 << i
+                        if cov: cov_run |= 1 << i
+                        info.append((pend, is_m, is_lit))
+                    for i in range(64):
+                        pend, is_m, is_lit = info[i]
+                        k = bin(mm_run & ((1 << i) - 1)).count("1")
+                        Lb = bin(litmask & ((1 << i) - 1)).count("1")
+                        if is_lit: out[op0 + 3 * k + Lb + 1] = fwd[i][0] & 0xFF
+                        if is_m:
+                            lit_k = i - pend
+                            out[op0 + 3 * k + Lb - lit_k] = (lit_k << 4) | mlo[i]
+                            o2 = op0 + 3 * k + Lb + 1
+                            out[o2:o2 + 2] = ((pos[i] - old[i]) & 0xFFFF).to_bytes(2, "little")
+                            if trace: print("  fast seq A=%d j=%d cand=%d lit=%d mlen=%d" % (A, i, old[i], lit_k, mlo[i]))
+                    op = op0 + 3 * bin(mm_run).count("1") + bin(litmask).count("1")
+                    covered |= cov_run
+                    nseq += bin(mm_run).count("1")
+                if f >= 64 or (f >= 49 and nseq > 0):
+                    if nseq == 0: continue_generic = True
+                    break
+                # ---- exact step for the search at probe lane f ----
+                j, sl = J[f], Sx[f]
+                x = sl if sl < j else j
                 if x >= 64:
                     if nseq == 0: continue_generic = True
                     break
                 pm = 0
                 if (nsing >> x) & 1:
                     pm = grp[x] & wrmask & ~covered & ((1 << x) - 1)
-                if x == j and pm == 0:
-                    lit = j - a; e = E[f]
-                    if trace: print("  fast seq A=%d j=%d cand=%d lit=%d mlen=%d" % (A, j, old[j], lit, mlo[j]))
-                    if lit < 15:
-                        v_opk[j] = op; v_lit[j] = lit; emit_mask |= 1 << j; op += 3 + lit
-                    else:
-                        emit_general(A + a, lit, A + j - old[j], e - j - 4)
+                if pm:
+                    pr = msb(pm); ok = fwd[pr][0] == fwd[x][0]; m_cand = A + pr; c = fwd[pr]
                 else:
-                    if pm:
-                        pr = msb(pm); ok = fwd[pr][0] == fwd[x][0]; m_cand = A + pr; c = fwd[pr]
-                    else:
-                        ok = vo[x]; m_cand = old[x]; c = cold[x]
-                    if not ok:
-                        f = x + 1; continue
-                    j = x; m_pos = A + j
-                    xa = ((fwd[j][2] ^ c[2]) << 32) | (fwd[j][1] ^ c[1]); xb = fwd[j][3] ^ c[3]
-                    if xa: mlen = ctz(xa) >> 3
-                    elif xb: mlen = 8 + (ctz(xb) >> 3)
-                    else: mlen = extend(src, m_pos, m_cand, 12, match_limit)
-                    lit = j - a
-                    if trace: print("  slow seq A=%d j=%d cand=%d lit=%d mlen=%d" % (A, j, m_cand, lit, mlen))
-                    emit_general(A + a, lit, m_pos - m_cand, mlen)
-                    e = j + 4 + mlen
-                    v_end[j] = e
-                match_mask |= 1 << j; nseq += 1
+                    ok = vo[x]; m_cand = old[x]; c = cold[x]
+                if not ok:
+                    f = x + 1; continue
+                j = x; m_pos = A + j
+                xa = ((fwd[j][2] ^ c[2]) << 32) | (fwd[j][1] ^ c[1]); xb = fwd[j][3] ^ c[3]
+                if xa: mlen = ctz(xa) >> 3
+                elif xb: mlen = 8 + (ctz(xb) >> 3)
+                else: mlen = extend(src, m_pos, m_cand, 12, match_limit)
+                lit = j - a
+                if trace: print("  slow seq A=%d j=%d cand=%d lit=%d mlen=%d" % (A, j, m_cand, lit, mlen))
+                emit_general(A + a, lit, m_pos - m_cand, mlen)
+                e = j + 4 + mlen
                 hi = min(e, 64)
-                covered |= ((1 << hi) - 1) & ~((2 << j) - 1)       # lanes j+1 .. e-1
-                anchor = A + e; a = e
+                covered |= ((1 << hi) - 1) & ~((2 << j) - 1)
+                nseq += 1
+                a = e
                 if e >= 64: break
                 f = e + 1
-                if f > RESTART: break
-            for i in range(64):
-                mb = match_mask & ((1 << i) - 1)
-                pj = msb(mb) if mb else 0
-                pend = v_end[pj] if mb else 0
-                mu = match_mask >> i
-                nj = i + ctz(mu) if mu else 64
-                if nj < 64 and i < nj and not (covered >> i) & 1 and (emit_mask >> nj) & 1:
-                    out[v_opk[nj] + 1 + (i - pend)] = fwd[i][0] & 0xFF
-                if (emit_mask >> i) & 1:
-                    out[v_opk[i]] = (v_lit[i] << 4) | mlo[i]
-                    out[v_opk[i] + 1 + v_lit[i] : v_opk[i] + 3 + v_lit[i]] = ((pos[i] - old[i]) & 0xFFFF).to_bytes(2, "little")
+            anchor = A + a
             inside = [bool((covered >> i) & 1) for i in range(64)]
             f_end = 64 if continue_generic else (64 if a >= 64 else a + 1)
             ins = sum(1 << i for i in range(64) if wr[i] and i < f_end and not inside[i])

@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void k_compress_fast(
         STAMP_DECL
         STAMP(0);   // table init
 
+        uint32_t guard = 0;      // every round of this loop consumes at least one input byte
         while (F0 < L) {                                                // :320
+            if (++guard > src_size) { failed = true; break; }           // unreachable; never spin on the GPU
             int32_t ub = -1;      // probe index of lane 0 of the next generic batch (-1 = pending insert pseudo-probe)
 
             // =====================================================================================
@@ -217,20 +219,67 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     J = mj ? lane + (uint32_t)__builtin_ctzll(mj) : 64u;
                     S = ms ? lane + (uint32_t)__builtin_ctzll(ms) : 64u;
                 }
-                uint32_t v_end = lane + kMinMatch + mlo;                          // anchor lane after a match at this lane
-                const uint32_t E = shfl(v_end, J & 63u);
+                const uint32_t v_end = lane + kMinMatch + mlo;                    // anchor lane after a match at this lane
 
                 uint32_t f = 1;          // next lane to probe
                 uint32_t a = 0;          // lane of the current anchor
                 uint32_t nseq = 0;
-                uint64_t match_mask = 0, emit_mask = 0;      // all match lanes / those emitted by the deferred stores
-                uint64_t covered = 0;                        // lanes strictly inside a match: never put() (Q6)
-                uint32_t v_opk = 0, v_lit = 0;
+                uint64_t covered = 0;    // lanes strictly inside a match: never put() (Q6)
                 bool continue_generic = false;
+                // with less than 512 bytes of room left every sequence takes the exact step, which checks the capacity
+                const bool tight = dst_len - op < 512u;
                 for (;;) {
-                    uint32_t j = 64u, s = 64u;
-                    if (f < 64u) { j = rdlane(J, f); s = rdlane(S, f); }
-                    const uint32_t x = s < j ? s : j;        // next lane that can possibly match
+                    // ---- fast run: a minimal scalar loop that only collects the match lanes.  A search that
+                    //      starts at f ends at J[f] when no slow lane comes first, the lane's hash is unique in the
+                    //      window (its probe reads the pre-window value whatever was put before) and the literal
+                    //      run fits the token nibble. ----
+                    const uint32_t a0 = a, op0 = op;
+                    uint64_t mm_run = 0;
+                    // (the restart threshold 49 only applies once the window has produced a match: a window without
+                    //  any match must scan all 64 lanes and hand the search over to the generic path)
+                    while (f < 64u && (f < 49u || (nseq == 0u && mm_run == 0))) {
+                        const uint32_t j = rdlane(J, f), sl = rdlane(S, f);
+                        if (tight || sl <= j || j - a >= 15u || ((nsing >> j) & 1ull)) break;
+                        mm_run |= 1ull << j;
+                        a = rdlane(v_end, j);                               // new anchor lane (:435)
+                        f = a + 1u;                                         // put(anchor) happens via `ins` below
+                    }
+                    if (mm_run) {
+                        // ---- flush the run: every offset from popcounts, three stores for all its sequences ----
+                        const uint64_t mb = mm_run & lanes_below;
+                        const bool has_prev = mb != 0;
+                        const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;   // previous match lane
+                        const uint32_t pend_all = shfl(v_end, pj);          // (unconditional: see zlz4_device.hpp)
+                        const uint32_t pend = has_prev ? pend_all : a0;     // first lane of my literal run
+                        const bool cov = has_prev && lane < pend;           // strictly inside the previous match
+                        const bool is_m = (mm_run & lane_bit) != 0;
+                        const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(mm_run);
+                        const bool is_lit = lane >= a0 && lane < jlast && !cov && !is_m;
+                        const uint64_t litmask = ballot(is_lit);
+                        const uint32_t k = (uint32_t)__popcll(mb);                          // sequences completed before me
+                        const uint32_t lb = (uint32_t)__popcll(litmask & lanes_below);      // literal bytes before me
+                        const uint32_t o1 = op0 + 3u * k + lb + 1u;
+                        if (is_lit) dst[o1] = (uint8_t)fwd.x;               // literals (:390)
+                        if (is_m) {
+                            const uint32_t lit_k = lane - pend;             // :360
+                            dst[o1 - 1u - lit_k] = (uint8_t)((lit_k << 4) | mlo);            // token
+                            const uint16_t off16 = (uint16_t)(pos - old);                    // :395
+                            __builtin_memcpy(dst + o1, &off16, 2);
+                        }
+                        const uint32_t nm = (uint32_t)__popcll(mm_run);
+                        op = op0 + 3u * nm + (uint32_t)__popcll(litmask);
+                        covered |= ballot(cov);
+                        nseq += nm;
+                        STAMP_COUNT(9);
+                    }
+                    if (f >= 64u || (f >= 49u && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
+                        if (nseq == 0u) continue_generic = true;    // every lane probed, no match
+                        break;
+                    }
+
+                    // ---- exact step for the probe at the first lane >= f that can match at all ----
+                    const uint32_t j0 = rdlane(J, f), s0 = rdlane(S, f);
+                    const uint32_t x = s0 < j0 ? s0 : j0;
                     if (x >= 64u) {
                         if (nseq == 0u) continue_generic = true;   // the search goes on past the window -> generic batches
                         // else: restart a fresh window at the current anchor (its lanes > a are re-probed there)
@@ -243,107 +292,55 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                         const uint64_t grp_x = (uint64_t)rdlane((uint32_t)grp, x) | ((uint64_t)rdlane((uint32_t)(grp >> 32), x) << 32);
                         pm = grp_x & wrmask & ~covered & ((1ull << x) - 1ull);
                     }
-                    uint32_t e;
-                    if (x == j && pm == 0) {
-                        // ---- the probe reads the pre-window value: everything is already in registers ----
-                        const uint32_t lit = j - a;
-                        e = rdlane(E, f);
-                        if (lit < 15u) {
-                            if (op + 3u + lit > dst_len) { failed = true; break; }
-                            v_opk = wrlane(op, j, v_opk);
-                            v_lit = wrlane(lit, j, v_lit);
-                            emit_mask |= 1ull << j;
-                            op += 3u + lit;
-                        } else {
-                            const uint32_t mlen = e - j - kMinMatch;
-                            const uint32_t nle = ext_len_bytes(lit);
-                            const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u;
-                            if (seq_end > dst_len) { failed = true; break; }
-                            const uint32_t offset = A + j - rdlane(old, j);
-                            if (lane == 0) dst[op] = (uint8_t)(0xF0u | mlen);
-                            write_ext_len(dst + op + 1u, lit, lane);
-                            uint8_t *o = dst + op + 1u + nle;
-                            if (lane >= a && lane < j) o[lane - a] = (uint8_t)fwd.x;
-                            if (lane < 2u) o[lit + lane] = (uint8_t)(offset >> (8u * lane));
-                            op = (uint32_t)seq_end;
-                        }
+                    uint32_t m_cand, cy, cz, cw;
+                    bool ok;
+                    if (pm) {
+                        const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
+                        ok = rdlane(fwd.x, pr) == rdlane(fwd.x, x);          // :348 (other tests hold in-window)
+                        m_cand = A + pr;
+                        cy = rdlane(fwd.y, pr); cz = rdlane(fwd.z, pr); cw = rdlane(fwd.w, pr);
                     } else {
-                        // ---- exact step: the slot was overwritten inside the window (pm != 0), or a long match ----
-                        uint32_t m_cand, cy, cz, cw;
-                        bool ok;
-                        if (pm) {
-                            const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
-                            ok = rdlane(fwd.x, pr) == rdlane(fwd.x, x);          // :348 (other tests hold in-window)
-                            m_cand = A + pr;
-                            cy = rdlane(fwd.y, pr); cz = rdlane(fwd.z, pr); cw = rdlane(fwd.w, pr);
-                        } else {
-                            ok = rdlane((uint32_t)vo, x) != 0;
-                            m_cand = rdlane(old, x);
-                            cy = rdlane(cold.y, x); cz = rdlane(cold.z, x); cw = rdlane(cold.w, x);
-                        }
-                        if (!ok) { STAMP_COUNT(11); f = x + 1u; continue; }      // probed, put, no match: next probe
-                        STAMP_COUNT(10);
-                        j = x;
-                        const uint32_t m_pos = A + j;
-                        const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ cz) << 32) | (rdlane(fwd.y, j) ^ cy);
-                        const uint32_t xb = rdlane(fwd.w, j) ^ cw;
-                        uint32_t mlen;
-                        if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
-                        else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
-                        else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
-                        // immediate emission (:360-432), literals = low bytes of lanes a..j-1
-                        const uint32_t lit = j - a;
-                        const uint32_t offset = m_pos - m_cand;
-                        const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
-                        const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
-                        if (seq_end > dst_len) { failed = true; break; }
-                        if (lane == 0)
-                            dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (mlen >= 15u ? 15u : mlen));
-                        if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
-                        uint8_t *o = dst + op + 1u + nle;
-                        if (lane >= a && lane < j) o[lane - a] = (uint8_t)fwd.x;
-                        o += lit;
-                        if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));
-                        if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
-                        op = (uint32_t)seq_end;
-                        e = j + kMinMatch + mlen;
-                        v_end = wrlane(e, j, v_end);
+                        ok = rdlane((uint32_t)vo, x) != 0;
+                        m_cand = rdlane(old, x);
+                        cy = rdlane(cold.y, x); cz = rdlane(cold.z, x); cw = rdlane(cold.w, x);
                     }
-                    STAMP_COUNT(9);
-                    // ---- after the match (:435-442) ----
-                    match_mask |= 1ull << j;
-                    nseq++;
+                    if (!ok) { STAMP_COUNT(11); f = x + 1u; continue; }      // probed, put, no match: next probe
+                    STAMP_COUNT(10);
+                    const uint32_t j = x;
+                    const uint32_t m_pos = A + j;
+                    const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ cz) << 32) | (rdlane(fwd.y, j) ^ cy);
+                    const uint32_t xb = rdlane(fwd.w, j) ^ cw;
+                    uint32_t mlen;
+                    if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
+                    else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
+                    else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
+                    // immediate emission (:360-432), literals = low bytes of lanes a..j-1
+                    const uint32_t lit = j - a;
+                    const uint32_t offset = m_pos - m_cand;
+                    const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
+                    const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
+                    if (seq_end > dst_len) { failed = true; break; }
+                    if (lane == 0)
+                        dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (mlen >= 15u ? 15u : mlen));
+                    if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
+                    uint8_t *o = dst + op + 1u + nle;
+                    if (lane >= a && lane < j) o[lane - a] = (uint8_t)fwd.x;
+                    o += lit;
+                    if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));
+                    if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
+                    op = (uint32_t)seq_end;
+                    const uint32_t e = j + kMinMatch + mlen;                // lane of the new anchor (may be >= 64)
                     {
                         const uint64_t upto_e = e >= 64u ? ~0ull : (1ull << e) - 1ull;
                         covered |= upto_e & ~((2ull << j) - 1ull);          // lanes j+1 .. e-1
                     }
-                    anchor = A + e;
+                    nseq++;
                     a = e;
-                    if (e >= 64u) break;                                // the next window inserts it as its lane 0
-                    f = e + 1u;                                         // put(anchor) :438-441: lane e is not `covered`
-                    if (f > 48u) break;                                 // few lanes left: start a fresh window
+                    if (e >= 64u) break;                                    // the next window inserts it as its lane 0
+                    f = e + 1u;
                 }
+                anchor = A + a;
                 STAMP(4);
-                // ---- which sequence every lane belongs to (vector, once per window) ----
-                const uint64_t mm_below = match_mask & lanes_below;
-                const bool has_prev = mm_below != 0;
-                const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mm_below) : 0u;   // previous match lane
-                // (the shuffle must run in ALL lanes: ds_bpermute returns 0 from source lanes that EXEC masks off)
-                const uint32_t pend_all = shfl(v_end, pj);
-                const uint32_t pend = has_prev ? pend_all : 0u;              // its end = first lane of my literal run
-                const bool inside = (covered & lane_bit) != 0;               // strictly inside a match: never put()
-                const uint64_t mm_up = match_mask >> lane;
-                const uint32_t nj = mm_up ? lane + (uint32_t)__builtin_ctzll(mm_up) : 64u;        // my sequence's match lane
-                const uint32_t base = shfl(v_opk, nj & 63u);
-                // ---- deferred emission of the simple sequences: 3 stores for the whole window ----
-                if (nj < 64u && lane < nj && !inside && ((emit_mask >> (nj & 63u)) & 1ull))
-                    dst[base + 1u + (lane - pend)] = (uint8_t)fwd.x;
-                if (emit_mask & lane_bit) {
-                    dst[v_opk] = (uint8_t)((v_lit << 4) | mlo);
-                    const uint16_t off16 = (uint16_t)(pos - old);
-                    __builtin_memcpy(dst + v_opk + 1u + v_lit, &off16, 2);
-                }
-                STAMP(6);
                 // lanes the serial loop put(): below the frontier and not strictly inside a match
                 const uint32_t f_end = continue_generic ? 64u : (a >= 64u ? 64u : a + 1u);
                 const uint64_t ins = wrmask & ~covered & (f_end >= 64u ? ~0ull : (1ull << f_end) - 1ull);
@@ -354,12 +351,15 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 if ((ins & lane_bit) && (grp & ins & ~lanes_below & ~lane_bit) == 0) table[h] = (T)pos;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 STAMP(5);
-                if (!continue_generic) {
+                if (!continue_generic && anchor != A) {
                     if (anchor < L) { has_ins = true; F0 = anchor + 1u; }
                     else { has_ins = false; F0 = L; }
                     continue;
                 }
-                ub = 63;      // same search, next probe index: lane 0 of the next batch is position F0 + 63
+                // continue_generic: same search, next probe index 63 (lane 0 of the next batch is position F0 + 63).
+                // (anchor == A without continue_generic cannot happen; if it ever did, the generic path below restarts
+                //  the search from F0 -- the table then holds exactly the anchor's put -- and always makes progress.)
+                if (continue_generic) ub = 63;
             }
 
             // =====================================================================================
