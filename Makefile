@@ -5,7 +5,7 @@ PKG     := zig-lz4_amd
 CSRC    := $(PKG)/csrc
 LIB     := $(PKG)/libzlz4_amd.so
 HIPSRC  := $(CSRC)/zlz4_capi.hip $(CSRC)/zlz4_frame.hip $(CSRC)/zlz4_decompress.hip \
-           $(CSRC)/zlz4_compress_fast.hip $(CSRC)/zlz4_compress_hc.hip
+           $(CSRC)/zlz4_compress_fast.hip $(CSRC)/zlz4_compress_hc.hip $(CSRC)/zlz4_compress_hc_serial.hip
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
 
 all: $(LIB) oracle

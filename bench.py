@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-mib", type=int, default=0)
+    ap.add_argument("--level", type=int, default=9, help="compressHC level for cfg4 (2..12)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,12 +163,12 @@ def main():
     defaults = {"cfg2": 65536, "cfg3": 1 << 20, "cfg4": 16384, "cfg5": 1024}
     block = (4 << 20) if args.workload == "cfg5" else 65536
     nblocks = args.blocks or defaults[args.workload]
-    hc_level = 9 if args.workload == "cfg4" else None
+    hc_level = args.level if args.workload == "cfg4" else None
     slot = (zl.compressBound(block) + 15) // 16 * 16          # 65 809 -> 65 824
     names = {
         "cfg2": "configs[1]: %d x 64 KiB blocks, compressDefault then decompressSafe (round trip), D-%s",
         "cfg3": "configs[2]: decompressSafe only, %d pre-compressed 64 KiB blocks, D-%s",
-        "cfg4": "configs[3]: compressHC level 9 then decompressSafe, %d x 64 KiB blocks, D-%s",
+        "cfg4": "configs[3]: compressHC level " + str(args.level) + " then decompressSafe, %d x 64 KiB blocks, D-%s",
         "cfg5": "configs[4]: lz4f frame, %d independent 4 MiB blocks per GPU, compressFrame then decompressFrame, D-%s",
     }
     workload = names[args.workload] % (nblocks, args.dist)

@@ -33,7 +33,7 @@ extern "C" {
 #define ZLZ4_ERR_ALLOCATION_FAILED     (-6)
 /* ---- new in this library ---- */
 #define ZLZ4_ERR_DEVICE                (-7)   /* HIP runtime / no gfx950 device / launch failure */
-#define ZLZ4_ERR_UNSUPPORTED           (-8)   /* level or acceleration not yet on the device path */
+#define ZLZ4_ERR_UNSUPPORTED           (-8)   /* reserved: a request the device path cannot serve (none at present) */
 
 /* ---- lz4f.Error (src/lz4f.zig:31-55): -(100 + 1-based declaration index) ---- */
 #define ZLZ4F_ERR_GENERIC                   (-101)
@@ -83,7 +83,7 @@ int64_t zlz4_compress_fast(const uint8_t *src, size_t src_len, uint8_t *dst, siz
                            uint32_t acceleration);
 
 /* replaces lz4hc.compressHC, src/lz4hc.zig:1440-1453.  Levels <2 -> 9, >12 -> 12 (:1445).
- * Levels 3..9 (hash chain) run on the device; 2 and 10..12 return ZLZ4_ERR_UNSUPPORTED. */
+ * All strategies of the level table (:72-86) run on the device: 2 lz4mid, 3..9 lz4hc, 10..12 lz4opt. */
 int64_t zlz4_compress_hc(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                          int32_t compression_level);
 

@@ -634,9 +634,305 @@ static int64_t compressHashChain(hc_ctx *ctx, const uint8_t *src, size_t inputSi
     return (int64_t)(op - dst);
 }
 
-/* src/lz4hc.zig:1440-1453 + :1457-1489.  Levels whose strategy is lz4mid (2) or
- * lz4opt (10-12) are SURVEY.md section 8(f) "next" rows and are not restated yet:
- * they return ZO_ERR_INVALID_STATE - 1000 so a test can never mistake them for parity. */
+/* ---------------- LZ4MID, level 2: src/lz4hc.zig:687-971 ---------------- */
+#define LZ4MID_HASHLOG 14
+#define LZ4MID_HASHTABLESIZE (1u << LZ4MID_HASHLOG)
+#define LZ4MID_HASHSIZE 8
+#define HASH_MULTIPLIER_64 58295818150454627ULL                         /* :51 */
+static inline uint32_t hashMid4Ptr(const uint8_t *p) {                  /* :139-146 */
+    return (uint32_t)(rd32(p) * HASH_MULTIPLIER) >> (32 - LZ4MID_HASHLOG);
+}
+static inline uint32_t hashMid8Ptr(const uint8_t *p) {                  /* :149-157 (hashes the low 56 bits) */
+    const uint64_t masked = rd64(p) << (64 - 56);
+    return (uint32_t)((masked * HASH_MULTIPLIER_64) >> (64 - LZ4MID_HASHLOG));
+}
+
+/* :789-818 / :899-928 "fill table with end of match" (identical in both branches) */
+static void mid_fill_end(uint32_t *hash4Table, uint32_t *hash8Table, const uint8_t *ip, const uint8_t *prefixPtr,
+                         uint32_t prefixIdx, const uint8_t *ilimit, uint32_t ilimitIdx) {
+    const uint32_t endMatchIdx = (uint32_t)((size_t)(ip - prefixPtr) + prefixIdx);
+    const uint32_t pos_m2 = endMatchIdx - 2;
+    if (pos_m2 < ilimitIdx) {
+        if ((size_t)(ip - prefixPtr) > 5) {
+            const uint8_t *ip5 = ip - 5;
+            if (ip5 <= ilimit) hash8Table[hashMid8Ptr(ip5)] = endMatchIdx - 5;
+        }
+        /* `@intFromPtr(ip) >= 3` etc. compare the ADDRESS with a small constant: always true */
+        { const uint8_t *ip3 = ip - 3; if (ip3 <= ilimit) hash8Table[hashMid8Ptr(ip3)] = endMatchIdx - 3; }
+        { const uint8_t *ip2 = ip - 2;
+          if (ip2 <= ilimit) { hash8Table[hashMid8Ptr(ip2)] = endMatchIdx - 2; hash4Table[hashMid4Ptr(ip2)] = endMatchIdx - 2; } }
+        { const uint8_t *ip1 = ip - 1; if (ip1 <= ilimit) hash4Table[hashMid4Ptr(ip1)] = endMatchIdx - 1; }
+    }
+}
+
+static int64_t compressMID(hc_ctx *ctx, const uint8_t *src, size_t inputSize, uint8_t *dst, size_t dstLen) {
+    const uint8_t *ip = src;
+    const uint8_t *anchor = ip;
+    const uint8_t *const iend = ip + inputSize;
+    uint8_t *op = dst;
+    uint8_t *const oend = op + dstLen;
+    if (inputSize < MFLIMIT + 1) return encodeLiterals(src, inputSize, dst, dstLen);     /* :706-708 */
+    const uint8_t *const mflimit = iend - MFLIMIT;                       /* :698 */
+    const uint8_t *const matchlimit = iend - LASTLITERALS;               /* :699 */
+    const uint8_t *const ilimit = iend - LZ4MID_HASHSIZE;                /* :700 */
+    ctx->nextToUpdate = 0; ctx->prefixStart = src; ctx->dictStart = src; ctx->dictLimit = 0; ctx->lowLimit = 0;   /* :711-716 */
+    uint32_t *hash4Table = ctx->hashTable;                               /* :721 */
+    uint32_t *hash8Table = ctx->hashTable + LZ4MID_HASHTABLESIZE;        /* :722 */
+    memset(hash4Table, 0, LZ4MID_HASHTABLESIZE * sizeof(uint32_t));      /* :725-726 */
+    memset(hash8Table, 0, LZ4MID_HASHTABLESIZE * sizeof(uint32_t));
+    const uint8_t *prefixPtr = ctx->prefixStart;
+    const uint32_t prefixIdx = ctx->dictLimit;
+    const uint32_t ilimitIdx = (uint32_t)((size_t)(ilimit - prefixPtr) + prefixIdx);     /* :730 */
+
+    while (ip <= mflimit) {                                              /* :733 */
+        const uint32_t ipIndex = (uint32_t)((size_t)(ip - prefixPtr) + prefixIdx);
+        uint32_t matchLength = 0, matchDistance = 0;
+        {   /* long match, 8-byte hash :739-824 */
+            const uint32_t h8 = hashMid8Ptr(ip);
+            const uint32_t pos8 = hash8Table[h8];
+            hash8Table[h8] = ipIndex;                                    /* :742 */
+            if (pos8 > 0 && ipIndex - pos8 <= LZ4_DISTANCE_MAX) {        /* :744 */
+                if (pos8 >= prefixIdx) {
+                    const uint8_t *matchPtr = prefixPtr + (pos8 - prefixIdx);
+                    if (matchPtr < ip) {                                 /* :748 */
+                        const size_t mlt = lz4Count(ip, matchPtr, matchlimit);          /* :749 (counts from ip) */
+                        if (mlt >= MINMATCH) {
+                            matchLength = (uint32_t)mlt;
+                            matchDistance = ipIndex - pos8;
+                            const uint32_t finalIpIndex = ipIndex;       /* :765 */
+                            if (ip + 1 <= ilimit) hash8Table[hashMid8Ptr(ip + 1)] = finalIpIndex + 1;   /* :767-769 */
+                            if (ip + 2 <= ilimit) hash8Table[hashMid8Ptr(ip + 2)] = finalIpIndex + 2;   /* :770-772 */
+                            if (ip + 1 <= ilimit) hash4Table[hashMid4Ptr(ip + 1)] = finalIpIndex + 1;   /* :773-775 */
+                            if (encodeSequence(&ip, &op, &anchor, (int32_t)matchLength, (int32_t)matchDistance, 1, oend) != 0)
+                                return ZO_ERR_OUTPUT_TOO_SMALL;          /* :777-788 */
+                            mid_fill_end(hash4Table, hash8Table, ip, prefixPtr, prefixIdx, ilimit, ilimitIdx);   /* :789-818 */
+                            continue;                                    /* :819 */
+                        }
+                    }
+                }
+            }
+        }
+        {   /* short match, 4-byte hash :827-934 */
+            const uint32_t h4 = hashMid4Ptr(ip);
+            const uint32_t pos4 = hash4Table[h4];
+            hash4Table[h4] = ipIndex;                                    /* :830 */
+            if (pos4 > 0 && ipIndex - pos4 <= LZ4_DISTANCE_MAX) {        /* :832 */
+                if (pos4 >= prefixIdx) {
+                    const uint8_t *matchPtr = prefixPtr + (pos4 - prefixIdx);
+                    if (matchPtr < ip) {
+                        matchLength = (uint32_t)lz4Count(ip, matchPtr, matchlimit);      /* :837 */
+                        if (matchLength >= MINMATCH) {
+                            matchDistance = ipIndex - pos4;
+                            if (ip < mflimit) {                          /* :842 */
+                                const uint32_t h8_next = hashMid8Ptr(ip + 1);
+                                const uint32_t pos8_next = hash8Table[h8_next];
+                                const uint32_t m2Distance = ipIndex + 1 - pos8_next;     /* :845 */
+                                if (m2Distance <= LZ4_DISTANCE_MAX && pos8_next >= prefixIdx && pos8_next > 0) {   /* :847 */
+                                    const uint8_t *m2Ptr = prefixPtr + (pos8_next - prefixIdx);
+                                    if (m2Ptr < ip + 1) {
+                                        const size_t ml2 = lz4Count(ip + 1, m2Ptr, matchlimit);
+                                        if (ml2 > matchLength) {         /* :851-856 */
+                                            hash8Table[h8_next] = ipIndex + 1;
+                                            ip += 1;
+                                            matchLength = (uint32_t)ml2;
+                                            matchDistance = m2Distance;
+                                        }
+                                    }
+                                }
+                            }
+                            const uint32_t finalIpIndex4 = ipIndex;      /* :873 -- the ORIGINAL index even if ip moved */
+                            if (ip + 1 <= ilimit) hash8Table[hashMid8Ptr(ip + 1)] = finalIpIndex4 + 1;   /* :875-877 */
+                            if (ip + 2 <= ilimit) hash8Table[hashMid8Ptr(ip + 2)] = finalIpIndex4 + 2;   /* :878-880 */
+                            if (ip + 1 <= ilimit) hash4Table[hashMid4Ptr(ip + 1)] = finalIpIndex4 + 1;   /* :881-883 */
+                            if (encodeSequence(&ip, &op, &anchor, (int32_t)matchLength, (int32_t)matchDistance, 1, oend) != 0)
+                                return ZO_ERR_OUTPUT_TOO_SMALL;          /* :886-897 */
+                            mid_fill_end(hash4Table, hash8Table, ip, prefixPtr, prefixIdx, ilimit, ilimitIdx);   /* :899-928 */
+                            continue;                                    /* :929 */
+                        }
+                    }
+                }
+            }
+        }
+        const size_t skipAmount = 1 + ((size_t)(ip - anchor) >> 9);      /* :937 */
+        ip += skipAmount;
+    }
+    const size_t finalLiterals = (size_t)(iend - anchor);                /* :942 */
+    if (finalLiterals > 0) {
+        if ((uintptr_t)op + finalLiterals + 1 > (uintptr_t)oend) return ZO_ERR_OUTPUT_TOO_SMALL;   /* :944 */
+        if (finalLiterals >= RUN_MASK) {
+            size_t len = finalLiterals - RUN_MASK;
+            op[0] = RUN_MASK << ML_BITS; op += 1;
+            while (len >= 255) { op[0] = 255; op += 1; len -= 255; }
+            op[0] = (uint8_t)len; op += 1;
+        } else {
+            op[0] = (uint8_t)(finalLiterals << ML_BITS); op += 1;
+        }
+        memcpy(op, anchor, finalLiterals);
+        op += finalLiterals;
+    }
+    return (int64_t)(op - dst);
+}
+
+/* ---------------- optimal parser, levels 10-12: src/lz4hc.zig:455-486, :1068-1391 ---------------- */
+#define LZ4_OPT_NUM (1 << 12)
+#define TRAILING_LITERALS 3
+typedef struct { int32_t price, off, mlen, litlen; } opt_match;          /* :456-461 */
+static inline int32_t literalsPrice(int32_t litlen) {                    /* :466-472 */
+    int32_t price = litlen;
+    if (litlen >= (int32_t)RUN_MASK) price += 1 + (litlen - (int32_t)RUN_MASK) / 255;
+    return price;
+}
+static inline int32_t sequencePrice(int32_t litlen, int32_t mlen) {      /* :476-486 */
+    int32_t price = 1 + 2;
+    price += literalsPrice(litlen);
+    if (mlen >= (int32_t)(ML_MASK + MINMATCH)) price += 1 + (mlen - (int32_t)(ML_MASK + MINMATCH)) / 255;
+    return price;
+}
+
+static int64_t compressOptimal(hc_ctx *ctx, const uint8_t *src, size_t inputSize, uint8_t *dst, size_t dstLen,
+                               int32_t nbSearches, size_t sufficientLen) {
+    opt_match *opt = (opt_match *)malloc((LZ4_OPT_NUM + TRAILING_LITERALS) * sizeof(opt_match));   /* :1079 */
+    if (!opt) return ZO_ERR_ALLOCATION_FAILED;
+    /* `opt` is `undefined` in the reference; the algorithm may read entries it has not written in this round
+     * (stale values of an earlier round).  Start from zero like a fresh stack page would most likely be. */
+    memset(opt, 0, (LZ4_OPT_NUM + TRAILING_LITERALS) * sizeof(opt_match));
+    const uint8_t *ip = src;
+    const uint8_t *anchor = ip;
+    const uint8_t *const iend = ip + inputSize;
+    uint8_t *op = dst;
+    uint8_t *const oend = op + dstLen;
+    int64_t ret;
+    if (inputSize < MFLIMIT + 1) { ret = encodeLiterals(src, inputSize, dst, dstLen); free(opt); return ret; }   /* :1092-1094 */
+    const uint8_t *const mflimit = iend - MFLIMIT;
+    const uint8_t *const matchlimit = iend - LASTLITERALS;
+    ctx->nextToUpdate = 0; ctx->prefixStart = src; ctx->dictStart = src; ctx->dictLimit = 0; ctx->lowLimit = 0;   /* :1097-1102 */
+    size_t sufficient_len = sufficientLen;                               /* :1105-1108 */
+    if (sufficient_len >= LZ4_OPT_NUM) sufficient_len = LZ4_OPT_NUM - 1;
+
+    while (ip <= mflimit) {                                              /* :1111 outer */
+        const int32_t llen = (int32_t)(ip - anchor);
+        insertHC(ctx, ip);                                               /* :1115 */
+        const hc_match firstMatch = insertAndGetWiderMatch(ctx, ip, ip, matchlimit, MINMATCH - 1, nbSearches, 1);
+        if (firstMatch.len == 0) { ip += 1; continue; }                  /* :1127 (never true: len starts at 3) */
+        if ((size_t)firstMatch.len > sufficient_len) {                   /* :1133 */
+            if (encodeSequence(&ip, &op, &anchor, firstMatch.len, firstMatch.off, 1, oend) != 0) { free(opt); return ZO_ERR_OUTPUT_TOO_SMALL; }
+            continue;
+        }
+        for (size_t rPos = 0; rPos < MINMATCH; rPos++) {                 /* :1150-1157 */
+            const int32_t cost = literalsPrice(llen + (int32_t)rPos);
+            opt[rPos].mlen = 1; opt[rPos].off = 0; opt[rPos].litlen = llen + (int32_t)rPos; opt[rPos].price = cost;
+        }
+        const size_t matchML = (size_t)firstMatch.len;                   /* :1160 */
+        const int32_t offset = firstMatch.off;
+        for (size_t mlen = MINMATCH; mlen <= matchML; mlen++) {          /* :1162-1169 */
+            const int32_t cost = sequencePrice(llen, (int32_t)mlen);
+            opt[mlen].mlen = (int32_t)mlen; opt[mlen].off = offset; opt[mlen].litlen = llen; opt[mlen].price = cost;
+        }
+        size_t last_match_pos = matchML;                                 /* :1171 */
+        for (size_t addLit = 1; addLit <= TRAILING_LITERALS; addLit++) { /* :1174-1180 */
+            opt[last_match_pos + addLit].mlen = 1; opt[last_match_pos + addLit].off = 0;
+            opt[last_match_pos + addLit].litlen = (int32_t)addLit;
+            opt[last_match_pos + addLit].price = opt[last_match_pos].price + literalsPrice((int32_t)addLit);
+        }
+        int encoded_early = 0;
+        size_t cur;
+        for (cur = 1; cur < last_match_pos; cur++) {                     /* :1183-1312 */
+            const uint8_t *curPtr = ip + cur;
+            if (curPtr > mflimit) break;                                 /* :1187 */
+            if (opt[cur + 1].price <= opt[cur].price) continue;          /* :1190 */
+            insertHC(ctx, curPtr);                                       /* :1193 */
+            const hc_match newMatch = insertAndGetWiderMatch(ctx, curPtr, curPtr, matchlimit, MINMATCH - 1, nbSearches, 1);
+            if (newMatch.len == 0) continue;                             /* :1205 */
+            if (((size_t)newMatch.len > sufficient_len) || (newMatch.len + (int32_t)cur >= (int32_t)LZ4_OPT_NUM)) {   /* :1208 */
+                const int32_t best_mlen = newMatch.len, best_off = newMatch.off;
+                size_t rp = 0;
+                while (rp < cur) {                                       /* :1217-1238 */
+                    const int32_t ml = opt[rp].mlen, off = opt[rp].off;
+                    if (ml == 1) { ip += 1; rp += 1; continue; }
+                    rp += (size_t)ml;
+                    if (encodeSequence(&ip, &op, &anchor, ml, off, 1, oend) != 0) { free(opt); return ZO_ERR_OUTPUT_TOO_SMALL; }
+                }
+                if (encodeSequence(&ip, &op, &anchor, best_mlen, best_off, 1, oend) != 0) { free(opt); return ZO_ERR_OUTPUT_TOO_SMALL; }
+                encoded_early = 1;                                       /* :1255 continue :outer */
+                break;
+            }
+            const int32_t baseLitlen = opt[cur].litlen;                  /* :1259 */
+            for (size_t litlen = 1; litlen < MINMATCH; litlen++) {       /* :1260-1270 */
+                const int32_t price = opt[cur].price - literalsPrice(baseLitlen) + literalsPrice(baseLitlen + (int32_t)litlen);
+                const size_t pos = cur + litlen;
+                if (price < opt[pos].price) {
+                    opt[pos].mlen = 1; opt[pos].off = 0; opt[pos].litlen = baseLitlen + (int32_t)litlen; opt[pos].price = price;
+                }
+            }
+            const size_t newMatchML = (size_t)newMatch.len;              /* :1273 */
+            for (size_t ml = MINMATCH; ml <= newMatchML; ml++) {         /* :1274-1302 */
+                const size_t pos = cur + ml;
+                const int32_t newOffset = newMatch.off;
+                int32_t price, ll;
+                if (opt[cur].mlen == 1) {
+                    ll = opt[cur].litlen;
+                    price = (cur > (size_t)ll) ? opt[cur - (size_t)ll].price : 0;
+                    price += sequencePrice(ll, (int32_t)ml);
+                } else {
+                    ll = 0;
+                    price = opt[cur].price + sequencePrice(0, (int32_t)ml);
+                }
+                if (pos > last_match_pos + TRAILING_LITERALS || price <= opt[pos].price) {   /* :1293 */
+                    if ((ml == newMatchML) && (last_match_pos < pos)) last_match_pos = pos;
+                    opt[pos].mlen = (int32_t)ml; opt[pos].off = newOffset; opt[pos].litlen = ll; opt[pos].price = price;
+                }
+            }
+            for (size_t addLit = 1; addLit <= TRAILING_LITERALS; addLit++) {     /* :1305-1311 */
+                opt[last_match_pos + addLit].mlen = 1; opt[last_match_pos + addLit].off = 0;
+                opt[last_match_pos + addLit].litlen = (int32_t)addLit;
+                opt[last_match_pos + addLit].price = opt[last_match_pos].price + literalsPrice((int32_t)addLit);
+            }
+        }
+        if (encoded_early) continue;
+        {   /* backtrack :1315-1332 */
+            const int32_t best_mlen = opt[last_match_pos].mlen, best_off = opt[last_match_pos].off;
+            cur = last_match_pos - (size_t)best_mlen;
+            size_t candidate_pos = cur;
+            int32_t selected_matchLength = best_mlen, selected_offset = best_off;
+            for (;;) {
+                const int32_t next_matchLength = opt[candidate_pos].mlen, next_offset = opt[candidate_pos].off;
+                opt[candidate_pos].mlen = selected_matchLength;
+                opt[candidate_pos].off = selected_offset;
+                selected_matchLength = next_matchLength;
+                selected_offset = next_offset;
+                if (next_matchLength > (int32_t)candidate_pos) break;
+                candidate_pos -= (size_t)next_matchLength;
+            }
+        }
+        {   /* encode :1335-1358 */
+            size_t rPos = 0;
+            while (rPos < last_match_pos) {
+                const int32_t ml = opt[rPos].mlen, off = opt[rPos].off;
+                if (ml == 1) { ip += 1; rPos += 1; continue; }
+                rPos += (size_t)ml;
+                if (encodeSequence(&ip, &op, &anchor, ml, off, 1, oend) != 0) { free(opt); return ZO_ERR_OUTPUT_TOO_SMALL; }
+            }
+        }
+    }
+    free(opt);
+    const size_t finalLiterals = (size_t)(iend - anchor);                /* :1362 */
+    if (finalLiterals > 0) {
+        if ((uintptr_t)op + finalLiterals + 1 > (uintptr_t)oend) return ZO_ERR_OUTPUT_TOO_SMALL;   /* :1364 */
+        if (finalLiterals >= RUN_MASK) {
+            size_t len = finalLiterals - RUN_MASK;
+            op[0] = RUN_MASK << ML_BITS; op += 1;
+            while (len >= 255) { op[0] = 255; op += 1; len -= 255; }
+            op[0] = (uint8_t)len; op += 1;
+        } else {
+            op[0] = (uint8_t)(finalLiterals << ML_BITS); op += 1;
+        }
+        memcpy(op, anchor, finalLiterals);
+        op += finalLiterals;
+    }
+    return (int64_t)(op - dst);
+}
+
+/* src/lz4hc.zig:1440-1453 + :1457-1489 */
 #define ZO_UNSUPPORTED_LEVEL (-1005)
 int64_t zo_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int32_t compressionLevel) {
     if (n > LZ4_MAX_INPUT_SIZE) return ZO_ERR_INPUT_TOO_LARGE;           /* :1442 */
@@ -648,10 +944,14 @@ int64_t zo_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, i
     if (level < 1) level = LZ4HC_CLEVEL_DEFAULT;                         /* :1465 */
     if (level > LZ4HC_CLEVEL_MAX) level = LZ4HC_CLEVEL_MAX;
     const clevel_params params = clevelTable[level];                     /* :1469, :88-97 */
-    if (params.strat != STRAT_HC) return ZO_UNSUPPORTED_LEVEL;
     hc_ctx *ctx = (hc_ctx *)calloc(1, sizeof(hc_ctx));                   /* Context.init() :405-419: zero tables */
     if (!ctx) return ZO_ERR_ALLOCATION_FAILED;
-    const int64_t r = compressHashChain(ctx, src, n, dst, cap, params.nbSearches);
+    int64_t r;
+    switch (params.strat) {                                              /* :1475-1488 */
+        case STRAT_HC:  r = compressHashChain(ctx, src, n, dst, cap, params.nbSearches); break;
+        case STRAT_MID: r = compressMID(ctx, src, n, dst, cap); break;
+        default:        r = compressOptimal(ctx, src, n, dst, cap, params.nbSearches, params.targetLength); break;
+    }
     free(ctx);
     return r;
 }
@@ -790,7 +1090,6 @@ int64_t zo_compress_frame(const uint8_t *src, size_t srcLen, uint8_t *dst, size_
             compressedSize = zo_compress_hc(srcBlock, blockLen, dstBlock, dstBlockLen, p->compression_level);
         else
             compressedSize = zo_compress_fast(srcBlock, blockLen, dstBlock, dstBlockLen, 1);
-        if (compressedSize == ZO_UNSUPPORTED_LEVEL) return ZO_UNSUPPORTED_LEVEL;
         if (compressedSize < 0) return mapCompressionError(compressedSize);
         const int storeUncompressed = (size_t)compressedSize >= blockLen;   /* :407 */
         const size_t actualSize = storeUncompressed ? blockLen : (size_t)compressedSize;

@@ -94,9 +94,10 @@ def test_decompress_malformed_status_parity(zl, oracle, gpu):
     _cmp(names, got, want)
 
 
-@pytest.mark.parametrize("level", [9, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("level", [9, 3, 4, 5, 6, 7, 8, 2, 10, 11, 12])
 def test_compress_hc_bit_exact(zl, oracle, gpu, level):
-    sel = ALL_INPUTS if level == 9 else [(n, b) for n, b in ALL_INPUTS if len(b) <= 70000]
+    """levels 3-9: hash chain kernels; 2: lz4mid; 10-12: lz4opt (incl. the reference's level-10 early-encode quirk)."""
+    sel = ALL_INPUTS if level in (9, 2) else [(n, b) for n, b in ALL_INPUTS if len(b) <= 70000]
     got = gh.compress_hc(zl, [b for _, b in sel], gpu, level)
     want = [oracle.compress_hc(b, level) for _, b in sel]
     _cmp([n for n, _ in sel], got, want)
@@ -137,6 +138,9 @@ def test_single_buffer_entry_points(zl, oracle, gpu):
         h = zl.compressHC(b, 9)
         assert h == oracle.compress_hc(b, 9), name
         assert zl.decompressSafe(h, len(b) + 7) == b, name
+    for name, b in cases.reference_test_inputs()[:8]:          # src/test_compat.zig:112-123 uses levels 2..12
+        for lvl in (2, 10, 12, 1, 0, 13, -3):                   # <2 -> 9, >12 -> 12 (src/lz4hc.zig:1445)
+            assert zl.compressHC(b, lvl) == oracle.compress_hc(b, lvl), (name, lvl)
     with pytest.raises(zl.Lz4Error) as e:
         zl.decompressSafe(b"\x1fA\x00\x00", 100)
     assert e.value.name == "CorruptedData"

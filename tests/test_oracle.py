@@ -67,6 +67,13 @@ def test_reference_inequalities(oracle):
     assert len(oracle.compress_hc(rnd, 9)) >= len(rnd)                       # src/test_lz4hc.zig:142
     for lvl in range(3, 9):                                                  # deeper search never hurts on this input
         assert len(oracle.compress_hc(cases.LOREM * 20, lvl + 1)) <= len(oracle.compress_hc(cases.LOREM * 20, lvl)) + 8
+    t = bytes(dg.text_bytes(30000, 2)) + cases.LOREM * 20
+    s9, s10, s11, s12 = (len(oracle.compress_hc(t, l)) for l in (9, 10, 11, 12))
+    assert s10 <= s9 and s11 <= s10 and s12 <= s11                           # src/test_lz4hc.zig:424-426
+    for lvl in (2, 11, 12):                                                  # every level the reference routes (:72-86)
+        for name, b in cases.reference_test_inputs():
+            if len(b) <= 100000:
+                assert oracle.decompress_safe(oracle.compress_hc(b, lvl), len(b)) == b, (name, lvl)
     assert oracle.compress_default(b"") == b"" and oracle.compress_hc(b"", 9) == b""   # src/test.zig:182, lz4hc.zig:1443
     assert oracle.decompress_safe(b"", 10) == b"" and oracle.decompress_safe(b"\x10A", 0) == b""   # lz4.zig:97-98
 
@@ -134,7 +141,7 @@ def test_cli_interop_oracle(oracle):
             open(a, "wb").write(d)
             subprocess.check_call([LZ4_CLI, "-f", "-q", a, o])
             assert oracle.decompress_frame(open(o, "rb").read(), len(d) + 8) == d
-        for lvl in range(3, 10):
+        for lvl in range(2, 13):                 # src/test_compat.zig:112-123 group 3: levels 2..12
             p = oracle.Prefs(); p.compression_level = lvl
             open(a, "wb").write(oracle.compress_frame(six[1], p))
             subprocess.check_call([LZ4_CLI, "-d", "-f", "-q", a, o])

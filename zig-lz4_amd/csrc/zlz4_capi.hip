@@ -177,8 +177,7 @@ int64_t zlz4_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
     if (n > ZLZ4_MAX_INPUT_SIZE) return ZLZ4_ERR_INPUT_TOO_LARGE;   // src/lz4hc.zig:1442
     if (n == 0) return 0;                                           // :1443
     if (cap == 0) return ZLZ4_ERR_OUTPUT_TOO_SMALL;                 // :1461
-    level = normalise_hc_level(level);
-    if (level < 3 || level > 9) return ZLZ4_ERR_UNSUPPORTED;        // lz4mid / lz4opt strategies: not on device yet
+    level = normalise_hc_level(level);                              // 2 lz4mid, 3-9 lz4hc, 10-12 lz4opt (:72-86)
     return run_single(Op::Hc, src, n, dst, cap, 0, level);
 }
 
@@ -215,7 +214,6 @@ int32_t zlz4_batch_compress_hc(void *stream, const uint8_t *d_in, const uint64_t
                                void *d_workspace, size_t workspace_bytes) {
     if (!device_ok()) return ZLZ4_ERR_DEVICE;
     level = normalise_hc_level(level);
-    if (level < 3 || level > 9) return ZLZ4_ERR_UNSUPPORTED;
     if (workspace_bytes < zlz4_hc_workspace_bytes(nblocks, max_in_len) || (!d_workspace && nblocks))
         return ZLZ4_ERR_INVALID_STATE;
     return zlz4_launch_compress_hc((hipStream_t)stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,

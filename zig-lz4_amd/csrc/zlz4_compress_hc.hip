@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
                                                     const uint32_t *__restrict__ d_in_len,
                                                     const T *__restrict__ d_link, uint64_t link_stride,
                                                     R *__restrict__ d_res, uint32_t blk0, uint32_t nblocks,
-                                                    int32_t max_attempts) {
+                                                    int32_t max_attempts, int32_t force_pattern_analysis) {
     const uint32_t b = blockIdx.y;
     if (b >= nblocks) return;
     const uint32_t n = d_in_len[blk0 + b];
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
     const uint8_t *src = d_in + d_in_off[blk0 + b];
     const T *link = d_link + (uint64_t)b * link_stride;
     const uint32_t limit = n - kLastLiterals;                    // iHighLimit = matchlimit :989, :1011
-    const bool pattern_analysis = max_attempts > 128;            // :983
+    // :983 for the hash-chain levels; compressOptimal always passes patternAnalysis = true (:1123, :1201)
+    const bool pattern_analysis = max_attempts > 128 || force_pattern_analysis != 0;
 
     // insertAndGetWiderMatch with iLowLimit == ip, longest = MINMATCH-1 (:522-534)
     const uint32_t lowest = p < 65536u ? 0u : p - kMaxDist;      // :553-554 (lowLimit == 0)
@@ -315,13 +316,29 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
     if (lane == 0) d_result[blk] = out;
 }
 
+}  // namespace zlz4
+
+extern "C" int zlz4_launch_hc_mid(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *, const uint64_t *,
+                                  const uint32_t *, int64_t *, uint32_t, void *, uint32_t);
+extern "C" int zlz4_launch_hc_opt_parse(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
+                                        const uint64_t *, const uint32_t *, int64_t *, const void *, uint64_t, int, void *,
+                                        uint32_t, uint32_t, uint32_t);
+extern "C" size_t zlz4_hc_mid_workspace_bytes(uint32_t chunk_blocks);
+extern "C" size_t zlz4_hc_opt_workspace_bytes(uint32_t chunk_blocks);
+
+namespace zlz4 {
+
+// K1 + K2 (+ K3 for the greedy levels, or the price-based parse for levels 10-12) in rounds of `chunk` blocks
 template <typename T, typename R>
 int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                       uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, int64_t *d_result,
-                      uint32_t nblocks, uint32_t max_in_len, int32_t max_attempts, void *ws, uint32_t chunk) {
+                      uint32_t nblocks, uint32_t max_in_len, int32_t max_attempts, void *ws, uint32_t chunk,
+                      bool optimal, uint32_t sufficient_len) {
     const uint64_t stride = ((uint64_t)max_in_len + 15u) & ~15ull;           // entries per block in both arrays
     T *d_link = static_cast<T *>(ws);
-    R *d_res = reinterpret_cast<R *>(static_cast<uint8_t *>(ws) + (uint64_t)chunk * stride * sizeof(T));
+    uint8_t *after_link = static_cast<uint8_t *>(ws) + (uint64_t)chunk * stride * sizeof(T);
+    R *d_res = reinterpret_cast<R *>(after_link);
+    void *d_opt = after_link + (uint64_t)chunk * stride * sizeof(R);
     const uint32_t np_max = max_in_len < 13u ? 1u : max_in_len - 11u;
     if (kHcTableSize * sizeof(T) > 65536u)   // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
@@ -331,9 +348,15 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
                            d_in_len, d_link, stride, b0, nb);
         hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 255u) / 256u, nb), dim3(256), 0, stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, d_res, b0, nb, max_attempts);
-        hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
-                           d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb);
+                           d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0);
+        if (optimal) {
+            const int rc = zlz4_launch_hc_opt_parse(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
+                                                    d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len);
+            if (rc != 0) return rc;
+        } else {
+            hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
+                               d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
@@ -341,12 +364,17 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
 }  // namespace zlz4
 
 namespace {
-constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per K1/K2/K3 round (bounds the workspace)
+constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per round (bounds the workspace)
 bool hc_small(uint32_t max_in_len) { return max_in_len <= 65536u; }
+uint64_t hc_per_block_bytes(uint32_t max_in_len) {
+    const uint64_t chain = (((uint64_t)max_in_len + 15u) & ~15ull) * (hc_small(max_in_len) ? 6u : 12u);   // links + results
+    const uint64_t opt = zlz4_hc_opt_workspace_bytes(1);                                                     // levels 10-12
+    const uint64_t mid = zlz4_hc_mid_workspace_bytes(1);                                                     // level 2
+    return chain + opt > mid ? chain + opt : mid;
+}
 uint32_t hc_chunk(uint32_t nblocks, uint32_t max_in_len) {
     // keep a round's workspace around <= 2 GiB for big blocks
-    const uint64_t per = (((uint64_t)max_in_len + 15u) & ~15ull) * (hc_small(max_in_len) ? 6u : 12u);
-    uint64_t c = (2ull << 30) / (per ? per : 1);
+    uint64_t c = (2ull << 30) / hc_per_block_bytes(max_in_len);
     if (c < 1) c = 1;
     if (c > kHcChunkBlocks) c = kHcChunkBlocks;
     if (c > nblocks) c = nblocks ? nblocks : 1;
@@ -354,24 +382,32 @@ uint32_t hc_chunk(uint32_t nblocks, uint32_t max_in_len) {
 }
 }  // namespace
 
+// one workspace size for every level (the caller need not know which strategy a level maps to)
 extern "C" size_t zlz4_hc_workspace_bytes(uint32_t nblocks, uint32_t max_in_len) {
-    const uint64_t stride = ((uint64_t)max_in_len + 15u) & ~15ull;
-    return (size_t)(hc_chunk(nblocks, max_in_len) * stride * (hc_small(max_in_len) ? 6u : 12u));
+    return (size_t)(hc_chunk(nblocks, max_in_len) * hc_per_block_bytes(max_in_len));
 }
 
-// src/lz4hc.zig:72-86: levels 3..9 -> nbSearches 4..256
+// src/lz4hc.zig:72-86: level 2 -> lz4mid; 3..9 -> lz4hc, nbSearches 4..256; 10..12 -> lz4opt (96/64, 512/128, 16384/4096)
 extern "C" int zlz4_launch_compress_hc(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
                                        const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                                        const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks,
                                        uint32_t max_in_len, int32_t level, void *ws, size_t ws_bytes) {
     if (nblocks == 0) return 0;
-    if (level < 3 || level > 9) return -8;
+    if (level < 2 || level > 12) return -8;
     if (ws_bytes < zlz4_hc_workspace_bytes(nblocks, max_in_len)) return -5;
-    const int32_t max_attempts = 1 << (level - 1);   // 3 -> 4 ... 9 -> 256
     const uint32_t chunk = hc_chunk(nblocks, max_in_len);
+    if (level == 2)
+        return zlz4_launch_hc_mid(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, ws, chunk);
+    const bool optimal = level >= 10;
+    static const int32_t opt_nb[3] = {96, 512, 16384};
+    static const uint32_t opt_target[3] = {64, 128, 4096};
+    const int32_t max_attempts = optimal ? opt_nb[level - 10] : 1 << (level - 1);   // 3 -> 4 ... 9 -> 256
+    const uint32_t sufficient = optimal ? opt_target[level - 10] : 0;
     if (hc_small(max_in_len))
         return zlz4::launch_hc_chunked<uint16_t, uint32_t>(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                                           d_result, nblocks, max_in_len, max_attempts, ws, chunk);
+                                                           d_result, nblocks, max_in_len, max_attempts, ws, chunk, optimal,
+                                                           sufficient);
     return zlz4::launch_hc_chunked<uint32_t, uint64_t>(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                                       d_result, nblocks, max_in_len, max_attempts, ws, chunk);
+                                                       d_result, nblocks, max_in_len, max_attempts, ws, chunk, optimal,
+                                                       sufficient);
 }

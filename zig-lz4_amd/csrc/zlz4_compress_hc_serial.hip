@@ -1,0 +1,387 @@
+// zlz4_compress_hc_serial.hip -- the two remaining compressHC strategies (reference src/lz4hc.zig:72-86):
+//   level 2      lz4mid  compressMID      (:687-971)   dual 4-byte / 8-byte hash tables, strictly serial
+//   level 10-12  lz4opt  compressOptimal  (:1068-1391) price-based parse over the hash-chain matches
+//
+// Both parses are serial inside a block and carry far more state than a wavefront can share cheaply
+// (128 KiB of tables for lz4mid, a 4099-entry price array for lz4opt), so here the batch dimension is the
+// parallel one: ONE LANE PER BLOCK runs the serial parse exactly as the reference does, 64 blocks per
+// wavefront, state in an HBM workspace.  The expensive part of lz4opt -- the match search
+// (insertAndGetWiderMatch, :538-681) -- does not run here: as for levels 3-9 the table state a search sees is
+// a pure function of the input, so K1/K2 of zlz4_compress_hc.hip produce the best match of every position
+// with full parallelism and this parse only looks results up.
+//
+// NOTE (reference behaviour, reproduced on purpose): the "match is good enough -> encode immediately" branch
+// of compressOptimal (:1207-1256) walks opt[] forward WITHOUT the reverse traversal of the normal path
+// (:1315-1332), i.e. it reads arrival records as if they were forward steps.  With targetLength 64 (level 10)
+// this is reached often and the emitted sequences are not always real matches: the reference's level-10
+// stream does not always decode.  Parity here means the same bytes as the reference, decodable or not.
+#include "zlz4_device.hpp"
+
+namespace zlz4 {
+
+constexpr uint32_t kMidHashLog = 14;                       // src/lz4hc.zig:45
+constexpr uint32_t kMidTableSize = 1u << kMidHashLog;      // :46
+constexpr uint64_t kHashMul64 = 58295818150454627ull;      // :51
+constexpr uint32_t kOptNum = 1u << 12;                     // :42
+constexpr uint32_t kTrailingLiterals = 3;                  // :1075
+constexpr uint32_t kOptEntries = kOptNum + kTrailingLiterals;
+
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint32_t hash_mid4(const uint8_t *p) { return (ld32(p) * kHashMul) >> (32 - kMidHashLog); }   // :139-146
+__device__ __forceinline__ uint32_t hash_mid8(const uint8_t *p) {                                                       // :149-157
+    return (uint32_t)(((ld64(p) << 8) * kHashMul64) >> (64 - kMidHashLog));
+}
+
+// lz4Count (:234-264) from absolute positions a (< limit) and b (< a); one lane
+__device__ __forceinline__ uint32_t count_from(const uint8_t *src, uint32_t a, uint32_t b, uint32_t limit) {
+    uint32_t c = 0;
+    while (a + 8u <= limit) {
+        const uint64_t x = ld64(src + a) ^ ld64(src + b);
+        if (x) return c + ((uint32_t)__builtin_ctzll(x) >> 3);
+        a += 8; b += 8; c += 8;
+    }
+    while (a < limit && src[a] == src[b]) { a++; b++; c++; }
+    return c;
+}
+
+// per-lane byte copy, 8 bytes at a time (ranges never overlap here: source is the input block)
+__device__ __forceinline__ void lane_copy(uint8_t *d, const uint8_t *s, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 8u <= n; k += 8u) { const uint64_t v = ld64(s + k); __builtin_memcpy(d + k, &v, 8); }
+    for (; k < n; k++) d[k] = s[k];
+}
+
+// encodeSequence (:308-386) with limitedOutput, one lane.  Returns false when the output does not fit.
+__device__ __forceinline__ bool encode_sequence_lane(const uint8_t *src, uint8_t *dst, uint32_t oend, uint32_t &ip,
+                                                     uint32_t &op, uint32_t &anchor, uint32_t match_len, uint32_t offset) {
+    const uint32_t lit = ip - anchor;                                             // :317
+    if ((uint64_t)op + lit / 255u + lit + (2u + 1u + kLastLiterals) > oend) return false;       // :320-325
+    const uint32_t tok = op++;
+    if (lit >= 15u) {                                                             // :331-343
+        uint32_t len = lit - 15u;
+        dst[tok] = 0xF0;
+        while (len >= 255u) { dst[op++] = 255; len -= 255u; }
+        dst[op++] = (uint8_t)len;
+    } else {
+        dst[tok] = (uint8_t)(lit << 4);
+    }
+    lane_copy(dst + op, src + anchor, lit);                                       // :346
+    op += lit;
+    dst[op] = (uint8_t)offset; dst[op + 1u] = (uint8_t)(offset >> 8);             // :350
+    op += 2;
+    const uint32_t ml_code = match_len - kMinMatch;                               // :354
+    if ((uint64_t)op + ml_code / 255u + (1u + kLastLiterals) > oend) return false;              // :355-359
+    if (ml_code >= 15u) {                                                         // :361-376 (510-steps == 255-run)
+        dst[tok] += 15;
+        uint32_t rem = ml_code - 15u;
+        while (rem >= 255u) { dst[op++] = 255; rem -= 255u; }
+        dst[op++] = (uint8_t)rem;
+    } else {
+        dst[tok] += (uint8_t)ml_code;
+    }
+    ip += match_len;                                                              // :382
+    anchor = ip;
+    return true;
+}
+
+// trailing literal-only sequence of compressMID / compressOptimal (:942-968, :1362-1388), one lane
+__device__ __forceinline__ int64_t final_literals_lane(const uint8_t *src, uint8_t *dst, uint32_t oend, uint32_t n,
+                                                       uint32_t anchor, uint32_t op) {
+    const uint32_t fl = n - anchor;
+    if (fl == 0) return (int64_t)op;
+    const uint32_t nle = ext_len_bytes(fl);
+    // the reference tests only op + fl + 1 and then writes the length-extension bytes unchecked (out of bounds
+    // when they do not fit); refuse instead of overrunning, as in k_hc_parse_emit
+    if ((uint64_t)op + fl + 1u > oend || (uint64_t)op + 1u + nle + fl > oend) return kErrOutputTooSmall;
+    if (fl >= 15u) {
+        uint32_t len = fl - 15u;
+        dst[op++] = 0xF0;
+        while (len >= 255u) { dst[op++] = 255; len -= 255u; }
+        dst[op++] = (uint8_t)len;
+    } else {
+        dst[op++] = (uint8_t)(fl << 4);
+    }
+    lane_copy(dst + op, src + anchor, fl);
+    return (int64_t)(op + fl);
+}
+
+// encodeLiterals (:1394-1425) for inputs shorter than 13 bytes, one lane
+__device__ __forceinline__ int64_t tiny_block_lane(const uint8_t *src, uint8_t *dst, uint32_t oend, uint32_t n) {
+    if (oend < n + 1u + n / 255u) return kErrOutputTooSmall;                      // :1395
+    dst[0] = (uint8_t)(n << 4);
+    for (uint32_t k = 0; k < n; k++) dst[1u + k] = src[k];
+    return (int64_t)n + 1;
+}
+
+// ------------------------------------------------------------------ level 2: compressMID, one lane per block
+// "fill table with end of match" (:789-818 == :899-928); e = index of the first byte after the match
+__device__ __forceinline__ void mid_fill_end(const uint8_t *src, uint32_t *h4, uint32_t *h8, uint32_t e, uint32_t ilimit) {
+    if (e - 2u < ilimit) {                                                        // pos_m2 < ilimitIdx
+        if (e > 5u && e - 5u <= ilimit) h8[hash_mid8(src + e - 5u)] = e - 5u;
+        // (`@intFromPtr(ip) >= 3` etc. compare an ADDRESS with a small constant: always true)
+        if (e - 3u <= ilimit) h8[hash_mid8(src + e - 3u)] = e - 3u;
+        if (e - 2u <= ilimit) { h8[hash_mid8(src + e - 2u)] = e - 2u; h4[hash_mid4(src + e - 2u)] = e - 2u; }
+        if (e - 1u <= ilimit) h4[hash_mid4(src + e - 1u)] = e - 1u;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_hc_mid_serial(const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
+                                                       const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
+                                                       const uint64_t *__restrict__ d_out_off,
+                                                       const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result,
+                                                       uint32_t *__restrict__ d_tables, uint32_t blk0, uint32_t nblocks) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t blk = blk0 + b;
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t n = d_in_len[blk], oend = d_out_cap[blk];
+    int64_t out;
+    if (n > kMaxInput) out = kErrInputTooLarge;                                   // :1442
+    else if (n == 0) out = 0;                                                     // :1443
+    else if (oend == 0) out = kErrOutputTooSmall;                                 // :1461
+    else if (n < kMfLimit + 1u) out = tiny_block_lane(src, dst, oend, n);         // :706-708
+    else {
+        uint32_t *h4 = d_tables + (uint64_t)b * (2u * kMidTableSize);             // :721-722 (zeroed by the launcher, :725-726)
+        uint32_t *h8 = h4 + kMidTableSize;
+        const uint32_t mflimit = n - kMfLimit, matchlimit = n - kLastLiterals, ilimit = n - 8u;   // :698-700
+        uint32_t ip = 0, anchor = 0, op = 0;
+        bool failed = false;
+        while (ip <= mflimit) {                                                   // :733
+            const uint32_t ip_index = ip;
+            bool taken = false;
+            {   // long match, 8-byte hash (:739-824)
+                const uint32_t hh = hash_mid8(src + ip);
+                const uint32_t pos8 = h8[hh];
+                h8[hh] = ip_index;                                                // :742
+                if (pos8 > 0 && ip_index - pos8 <= kMaxDist && pos8 < ip) {       // :744-748
+                    const uint32_t mlt = count_from(src, ip, pos8, matchlimit);   // :749
+                    if (mlt >= kMinMatch) {
+                        if (ip + 1u <= ilimit) h8[hash_mid8(src + ip + 1u)] = ip_index + 1u;     // :767-769
+                        if (ip + 2u <= ilimit) h8[hash_mid8(src + ip + 2u)] = ip_index + 2u;     // :770-772
+                        if (ip + 1u <= ilimit) h4[hash_mid4(src + ip + 1u)] = ip_index + 1u;     // :773-775
+                        if (!encode_sequence_lane(src, dst, oend, ip, op, anchor, mlt, ip_index - pos8)) { failed = true; break; }
+                        mid_fill_end(src, h4, h8, ip, ilimit);                    // :789-818
+                        taken = true;
+                    }
+                }
+            }
+            if (taken) continue;                                                  // :819
+            {   // short match, 4-byte hash (:827-934)
+                const uint32_t hh = hash_mid4(src + ip);
+                const uint32_t pos4 = h4[hh];
+                h4[hh] = ip_index;                                                // :830
+                if (pos4 > 0 && ip_index - pos4 <= kMaxDist && pos4 < ip) {       // :832-836
+                    uint32_t match_len = count_from(src, ip, pos4, matchlimit);   // :837
+                    if (match_len >= kMinMatch) {
+                        uint32_t match_dist = ip_index - pos4;
+                        if (ip < mflimit) {                                       // :842
+                            const uint32_t h8n = hash_mid8(src + ip + 1u);
+                            const uint32_t pos8n = h8[h8n];
+                            const uint32_t m2_dist = ip_index + 1u - pos8n;       // :845
+                            if (m2_dist <= kMaxDist && pos8n > 0 && pos8n < ip + 1u) {   // :847-849
+                                const uint32_t ml2 = count_from(src, ip + 1u, pos8n, matchlimit);
+                                if (ml2 > match_len) {                            // :851-856
+                                    h8[h8n] = ip_index + 1u;
+                                    ip += 1;
+                                    match_len = ml2;
+                                    match_dist = m2_dist;
+                                }
+                            }
+                        }
+                        // :873 finalIpIndex4 = the ORIGINAL index even when ip has moved by one
+                        if (ip + 1u <= ilimit) h8[hash_mid8(src + ip + 1u)] = ip_index + 1u;     // :875-877
+                        if (ip + 2u <= ilimit) h8[hash_mid8(src + ip + 2u)] = ip_index + 2u;     // :878-880
+                        if (ip + 1u <= ilimit) h4[hash_mid4(src + ip + 1u)] = ip_index + 1u;     // :881-883
+                        if (!encode_sequence_lane(src, dst, oend, ip, op, anchor, match_len, match_dist)) { failed = true; break; }
+                        mid_fill_end(src, h4, h8, ip, ilimit);                    // :899-928
+                        taken = true;
+                    }
+                }
+            }
+            if (taken) continue;                                                  // :929
+            ip += 1u + ((ip - anchor) >> 9);                                      // :937-938
+        }
+        out = failed ? kErrOutputTooSmall : final_literals_lane(src, dst, oend, n, anchor, op);
+    }
+    d_result[blk] = out;
+}
+
+// ------------------------------------------------------------------ levels 10-12: compressOptimal parse, one lane per block
+struct OptEntry { int32_t price, off, mlen, litlen; };                            // :456-461
+
+__device__ __forceinline__ int32_t literals_price(int32_t litlen) {               // :466-472
+    int32_t price = litlen;
+    if (litlen >= 15) price += 1 + (litlen - 15) / 255;
+    return price;
+}
+__device__ __forceinline__ int32_t sequence_price(int32_t litlen, int32_t mlen) { // :476-486
+    int32_t price = 1 + 2 + literals_price(litlen);
+    if (mlen >= 19) price += 1 + (mlen - 19) / 255;
+    return price;
+}
+
+template <typename R>   // R = K2's packed result (len | off << 16, or len | off << 32)
+__global__ __launch_bounds__(64) void k_hc_opt_parse(const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
+                                                      const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
+                                                      const uint64_t *__restrict__ d_out_off,
+                                                      const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result,
+                                                      const R *__restrict__ d_res, uint64_t res_stride,
+                                                      OptEntry *__restrict__ d_opt, uint32_t blk0, uint32_t nblocks,
+                                                      uint32_t sufficient_len_in) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t blk = blk0 + b;
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t n = d_in_len[blk], oend = d_out_cap[blk];
+    int64_t out;
+    if (n > kMaxInput) out = kErrInputTooLarge;
+    else if (n == 0) out = 0;
+    else if (oend == 0) out = kErrOutputTooSmall;
+    else if (n < kMfLimit + 1u) out = tiny_block_lane(src, dst, oend, n);         // :1092-1094
+    else {
+        const R *res = d_res + (uint64_t)b * res_stride;
+        OptEntry *opt = d_opt + (uint64_t)b * kOptEntries;                        // :1079
+        const uint32_t mflimit = n - kMfLimit;
+        uint32_t sufficient_len = sufficient_len_in;                              // :1105-1108
+        if (sufficient_len >= kOptNum) sufficient_len = kOptNum - 1u;
+        auto best_match = [&](uint32_t p, int32_t &len, int32_t &off) {           // insertHC + insertAndGetWiderMatch result at p
+            const R r = res[p];
+            if (sizeof(R) == 4) { len = (int32_t)((uint32_t)r & 0xFFFFu); off = (int32_t)((uint32_t)r >> 16); }
+            else { len = (int32_t)(uint32_t)r; off = (int32_t)((uint64_t)r >> 32); }
+        };
+        uint32_t ip = 0, anchor = 0, op = 0;
+        bool failed = false;
+        while (ip <= mflimit && !failed) {                                        // :1111
+            const int32_t llen = (int32_t)(ip - anchor);
+            int32_t first_len, first_off;
+            best_match(ip, first_len, first_off);                                 // :1115-1125
+            if (first_len == 0) { ip += 1; continue; }                            // :1127 (never true: the result starts at 3)
+            if ((uint32_t)first_len > sufficient_len) {                           // :1133-1147
+                if (!encode_sequence_lane(src, dst, oend, ip, op, anchor, (uint32_t)first_len, (uint32_t)first_off)) failed = true;
+                continue;
+            }
+            for (uint32_t r = 0; r < kMinMatch; r++) {                            // :1150-1157
+                opt[r].mlen = 1; opt[r].off = 0; opt[r].litlen = llen + (int32_t)r; opt[r].price = literals_price(llen + (int32_t)r);
+            }
+            const uint32_t match_ml = (uint32_t)first_len;                        // :1160
+            for (uint32_t ml = kMinMatch; ml <= match_ml; ml++) {                 // :1162-1169
+                opt[ml].mlen = (int32_t)ml; opt[ml].off = first_off; opt[ml].litlen = llen; opt[ml].price = sequence_price(llen, (int32_t)ml);
+            }
+            uint32_t last_match_pos = match_ml;                                   // :1171
+            for (uint32_t al = 1; al <= kTrailingLiterals; al++) {                // :1174-1180
+                OptEntry &e = opt[last_match_pos + al];
+                e.mlen = 1; e.off = 0; e.litlen = (int32_t)al; e.price = opt[last_match_pos].price + literals_price((int32_t)al);
+            }
+            bool encoded_early = false;
+            for (uint32_t cur = 1; cur < last_match_pos; cur++) {                 // :1183-1312
+                const uint32_t cur_pos = ip + cur;
+                if (cur_pos > mflimit) break;                                     // :1187
+                if (opt[cur + 1u].price <= opt[cur].price) continue;              // :1190
+                int32_t new_len, new_off;
+                best_match(cur_pos, new_len, new_off);                            // :1193-1203
+                if (new_len == 0) continue;                                       // :1205
+                if (((uint32_t)new_len > sufficient_len) || (new_len + (int32_t)cur >= (int32_t)kOptNum)) {   // :1208
+                    uint32_t rp = 0;                                              // :1216-1238 (forward walk, no reverse traversal)
+                    while (rp < cur) {
+                        const int32_t ml = opt[rp].mlen, off = opt[rp].off;
+                        if (ml == 1) { ip += 1; rp += 1; continue; }
+                        rp += (uint32_t)ml;
+                        if (!encode_sequence_lane(src, dst, oend, ip, op, anchor, (uint32_t)ml, (uint32_t)off)) { failed = true; break; }
+                    }
+                    if (!failed && !encode_sequence_lane(src, dst, oend, ip, op, anchor, (uint32_t)new_len, (uint32_t)new_off)) failed = true;   // :1241-1252
+                    encoded_early = true;                                         // :1255
+                    break;
+                }
+                const int32_t base_litlen = opt[cur].litlen;                      // :1259
+                for (uint32_t ll = 1; ll < kMinMatch; ll++) {                     // :1260-1270
+                    const int32_t price = opt[cur].price - literals_price(base_litlen) + literals_price(base_litlen + (int32_t)ll);
+                    OptEntry &e = opt[cur + ll];
+                    if (price < e.price) { e.mlen = 1; e.off = 0; e.litlen = base_litlen + (int32_t)ll; e.price = price; }
+                }
+                const uint32_t new_ml = (uint32_t)new_len;                        // :1273
+                const OptEntry oc = opt[cur];
+                for (uint32_t ml = kMinMatch; ml <= new_ml; ml++) {               // :1274-1302
+                    const uint32_t pos = cur + ml;
+                    int32_t price, ll;
+                    if (oc.mlen == 1) {
+                        ll = oc.litlen;
+                        price = (cur > (uint32_t)ll) ? opt[cur - (uint32_t)ll].price : 0;
+                        price += sequence_price(ll, (int32_t)ml);
+                    } else {
+                        ll = 0;
+                        price = oc.price + sequence_price(0, (int32_t)ml);
+                    }
+                    if (pos > last_match_pos + kTrailingLiterals || price <= opt[pos].price) {   // :1293
+                        if (ml == new_ml && last_match_pos < pos) last_match_pos = pos;
+                        OptEntry &e = opt[pos];
+                        e.mlen = (int32_t)ml; e.off = new_off; e.litlen = ll; e.price = price;
+                    }
+                }
+                for (uint32_t al = 1; al <= kTrailingLiterals; al++) {            // :1305-1311
+                    OptEntry &e = opt[last_match_pos + al];
+                    e.mlen = 1; e.off = 0; e.litlen = (int32_t)al; e.price = opt[last_match_pos].price + literals_price((int32_t)al);
+                }
+            }
+            if (encoded_early || failed) continue;
+            {   // reverse traversal (:1315-1332)
+                int32_t sel_ml = opt[last_match_pos].mlen, sel_off = opt[last_match_pos].off;
+                uint32_t cand = last_match_pos - (uint32_t)sel_ml;
+                for (;;) {
+                    const int32_t next_ml = opt[cand].mlen, next_off = opt[cand].off;
+                    opt[cand].mlen = sel_ml; opt[cand].off = sel_off;
+                    sel_ml = next_ml; sel_off = next_off;
+                    if (next_ml > (int32_t)cand) break;
+                    cand -= (uint32_t)next_ml;
+                }
+            }
+            uint32_t rp = 0;                                                      // :1335-1358
+            while (rp < last_match_pos) {
+                const int32_t ml = opt[rp].mlen, off = opt[rp].off;
+                if (ml == 1) { ip += 1; rp += 1; continue; }
+                rp += (uint32_t)ml;
+                if (!encode_sequence_lane(src, dst, oend, ip, op, anchor, (uint32_t)ml, (uint32_t)off)) { failed = true; break; }
+            }
+        }
+        out = failed ? kErrOutputTooSmall : final_literals_lane(src, dst, oend, n, anchor, op);
+    }
+    d_result[blk] = out;
+}
+
+}  // namespace zlz4
+
+extern "C" size_t zlz4_hc_mid_workspace_bytes(uint32_t chunk_blocks) {
+    return (size_t)chunk_blocks * 2u * zlz4::kMidTableSize * sizeof(uint32_t);
+}
+extern "C" size_t zlz4_hc_opt_workspace_bytes(uint32_t chunk_blocks) {
+    return (size_t)chunk_blocks * zlz4::kOptEntries * sizeof(zlz4::OptEntry);
+}
+
+extern "C" int zlz4_launch_hc_mid(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                  uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, int64_t *d_result,
+                                  uint32_t nblocks, void *ws, uint32_t chunk) {
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
+        const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+        if (hipMemsetAsync(ws, 0, zlz4_hc_mid_workspace_bytes(nb), stream) != hipSuccess) return -7;   // :725-726
+        hipLaunchKernelGGL(zlz4::k_hc_mid_serial, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len, d_out,
+                           d_out_off, d_out_cap, d_result, static_cast<uint32_t *>(ws), b0, nb);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -7;
+}
+
+// parse of one chunk whose K2 results are already in d_res (called from zlz4_compress_hc.hip's chunk loop)
+extern "C" int zlz4_launch_hc_opt_parse(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
+                                        const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                        const uint32_t *d_out_cap, int64_t *d_result, const void *d_res, uint64_t res_stride,
+                                        int wide, void *d_opt, uint32_t b0, uint32_t nb, uint32_t sufficient_len) {
+    if (wide)
+        hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint64_t>, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len,
+                           d_out, d_out_off, d_out_cap, d_result, static_cast<const uint64_t *>(d_res), res_stride,
+                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len);
+    else
+        hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint32_t>, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len,
+                           d_out, d_out_off, d_out_cap, d_result, static_cast<const uint32_t *>(d_res), res_stride,
+                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len);
+    return hipGetLastError() == hipSuccess ? 0 : -7;
+}

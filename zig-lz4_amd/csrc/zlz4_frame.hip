@@ -421,7 +421,6 @@ int64_t zlz4f_compress_frame_device(void *stream_, const uint8_t *d_src, size_t 
     int32_t hc_level = 0;
     if (p.compression_level > 0) {
         hc_level = p.compression_level < 2 ? 9 : (p.compression_level > 12 ? 12 : p.compression_level);
-        if (hc_level < 3 || hc_level > 9) return ZLZ4_ERR_UNSUPPORTED;
     }
     const uint64_t slot = (zlz4_compress_bound(bs) + 15) & ~15ull;
     DevBuf d_plan(4 * sizeof(int64_t));
