@@ -286,8 +286,15 @@ def main():
         clen[0] = csize.to(torch.int32)
         do_decompress()
         torch.cuda.synchronize()
-        assert bool((dsize == block).all()), "decompress size mismatch"
-        assert torch.equal(out, inp), "round trip mismatch"
+        if hc_level in (10, 11):
+            # the reference's lz4opt early-encode branch (src/lz4hc.zig:1207-1256) emits streams that do not always
+            # decode (every 64 KiB D-text block at level 10, a few percent at level 11); bit-exactness is checked
+            # against the oracle's bytes by the cpu_baseline leg / tests, not by a round trip
+            nbad = int(((dsize != block) | (out != inp).any(dim=1)).sum())
+            log("[rank %d] level %d: %d of %d blocks do not round-trip (reference behaviour)" % (rank, hc_level, nbad, nblocks))
+        else:
+            assert bool((dsize == block).all()), "decompress size mismatch"
+            assert torch.equal(out, inp), "round trip mismatch"
         total_c = int(csize.sum())
         sample_src = inp
         csize_head = [int(x) for x in csize[:4].cpu()]
