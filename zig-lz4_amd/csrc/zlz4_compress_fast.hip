@@ -514,8 +514,9 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
     // experiment knob: extra dynamic LDS per workgroup lowers the number of resident waves per CU
     static const uint32_t lds_pad = [] { const char *e = getenv("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
     // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
+    static const uint32_t tune_wpw = [] { const char *e = getenv("ZLZ4_TUNE_WPW"); return e ? (uint32_t)atoi(e) : 0u; }();
     if (max_in_len <= 65536u + 11u) {
-        const uint32_t wpw = 4;   // 4 x 8 KiB = 32 KiB LDS per workgroup -> 5 workgroups (20 waves) per CU
+        const uint32_t wpw = (tune_wpw == 1 || tune_wpw == 2) ? tune_wpw : 4;   // 4 x 8 KiB = 32 KiB LDS per workgroup -> 5 workgroups (20 waves) per CU
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint16_t) + lds_pad, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
                            d_out_cap, d_result, nblocks, acceleration);
