@@ -1,0 +1,23 @@
+"""The one-lane-per-block decoder (used for batches >= 16384 blocks) through the same parity tests as the
+wave-per-block decoder: a child pytest process with ZLZ4_DECOMP_LANE_MIN=1 (the threshold is read once per
+process) runs every decompress / frame-decode test."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lane_decoder_passes_the_decoder_parity_tests(gpu):
+    if os.environ.get("ZLZ4_DECOMP_LANE_MIN") == "1":
+        pytest.skip("already inside the child run")
+    env = dict(os.environ, ZLZ4_DECOMP_LANE_MIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_frame.py"),
+                        "-k", "decompress or batch_of or single_buffer or interop"],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

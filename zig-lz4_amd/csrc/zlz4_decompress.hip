@@ -12,6 +12,8 @@
 // ones and matches are copied 16 B per lane.  Overlapping matches
 // (offset < matchLength, src/lz4.zig:235-241) use the periodic-extension
 // identity out[op+k] = out[op-offset + (k mod offset)].
+#include <cstdlib>
+
 #include "zlz4_device.hpp"
 
 namespace zlz4 {
@@ -160,12 +162,162 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
     if (lane == 0) d_result[blk] = res;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One LANE per block (large batches).  The wave-per-block kernel above spends ~50 scalar instructions per
+// sequence on the single scalar unit of a CU; here every instruction serves 64 blocks at once and the copies
+// are per-lane 16-byte chunk moves.  Same decision order / error codes as decompressGeneric.
+// Chunk copies may write up to 15 bytes past the end of a literal run or match, but never past dst + cap and
+// only ahead of the write position, where later output overwrites them (bytes between the returned size and
+// the capacity are unspecified, as in every wild-copy LZ4 decoder).  Output regions of different blocks must
+// therefore not overlap (the frame decoder passes the exact block size as capacity).
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+__global__ __launch_bounds__(64) void k_decompress_lane(
+    const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
+    const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
+    const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks) {
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim.x = active lanes per wavefront
+    if (blk >= nblocks) return;
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t iend = d_in_len[blk], oend = d_out_cap[blk];
+    int64_t res = 0;
+    uint32_t ip = 0, op = 0;
+    if (iend != 0 && oend != 0) {                                   // src/lz4.zig:97-98
+        // 16-byte look-ahead at the next token: one load yields token, <= 13 literals and the offset, and it is
+        // issued before the copies of the previous sequence so the two round trips overlap
+        u32x4 w = {0, 0, 0, 0};
+        bool have_w = false;
+        if (16u <= iend) { w = ld128(src); have_w = true; }
+        for (;;) {
+            if (ip >= iend) break;                                  // :113
+            if (have_w) {
+                const uint32_t tok = w.x & 0xFFu;
+                const uint32_t lit = tok >> 4, mlc = tok & 15u;
+                // fast path: no length extension, header + literals inside the 16 bytes, room for chunk stores
+                if (lit <= 13u && mlc != 15u && op + lit + 48u <= oend) {
+                    // (ip + 16 <= iend holds, so the literals fit (:136) and the offset is present (:146, :149);
+                    //  op + lit + 48 <= oend covers :137 and :174 and keeps every chunk store inside dst)
+                    const uint32_t oi = 1u + lit;                   // byte index of the offset inside w
+                    const uint32_t d0 = oi >> 2, sh = (oi & 3u) * 8u;
+                    const uint32_t lo = d0 == 0 ? w.x : (d0 == 1 ? w.y : (d0 == 2 ? w.z : w.w));
+                    const uint32_t hi = d0 == 0 ? w.y : (d0 == 1 ? w.z : w.w);     // d0 == 3 only with sh <= 16
+                    const uint32_t offset = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 0xFFFFu;   // :150
+                    const uint32_t nip = ip + 3u + lit;
+                    u32x4 wn = {0, 0, 0, 0};
+                    const bool have_n = nip + 16u <= iend;
+                    if (have_n) wn = ld128(src + nip);              // next header: in flight during the copies
+                    u32x4 ls;                                       // literals = bytes 1..lit of w (:140), chunk store
+                    ls.x = (w.x >> 8) | (w.y << 24); ls.y = (w.y >> 8) | (w.z << 24);
+                    ls.z = (w.z >> 8) | (w.w << 24); ls.w = w.w >> 8;
+                    st128(dst + op, ls);
+                    op += lit;
+                    ip = nip;
+                    if (offset == 0) { res = kErrCorrupted; break; }            // :154
+                    const uint32_t ml = mlc + kMinMatch;                        // :171 (4..18)
+                    if (offset > op) { res = kErrCorrupted; break; }            // :181-186 / :231
+                    const uint8_t *m = dst + (op - offset);
+                    uint8_t *o = dst + op;
+                    if (offset >= 16u) {
+                        st128(o, ld128(m));
+                        if (ml > 16u) st128(o + 16u, ld128(m + 16u));
+                    } else if (offset >= 8u) {
+                        for (uint32_t k = 0; k < ml; k += 8u) { const uint64_t v = ld64u(m + k); __builtin_memcpy(o + k, &v, 8); }
+                    } else {
+                        for (uint32_t k = 0; k < ml; k++) o[k] = m[k];          // :238-240
+                    }
+                    op += ml;
+                    w = wn;
+                    have_w = have_n;
+                    continue;
+                }
+            }
+            // ---- general path (length extensions, long literal runs, end of the stream / output, malformed input) ----
+            const uint32_t token = src[ip];                         // :116
+            ip += 1;
+            uint32_t lit = token >> 4;                              // :120
+            if (lit == 15u) {                                       // :123-131
+                bool bad = false;
+                for (;;) {
+                    if (ip >= iend) { bad = true; break; }          // :125
+                    const uint32_t s = src[ip];
+                    ip += 1;
+                    lit += s;
+                    if (lit > 0xFFFF0000u) lit = 0xFFFF0000u;       // saturate (can only end in an error)
+                    if (s != 255u) break;
+                }
+                if (bad) { res = kErrCorrupted; break; }
+            }
+            if (lit > 0) {                                          // :134
+                if (lit > iend - ip) { res = kErrCorrupted; break; }        // :136
+                if (lit > oend - op) { res = kErrOutputTooSmall; break; }   // :137
+                uint32_t k = 0;                                     // :140
+                while (k < lit && ip + k + 16u <= iend && op + k + 16u <= oend) {
+                    st128(dst + op + k, ld128(src + ip + k));
+                    k += 16u;
+                }
+                for (; k < lit; k++) dst[op + k] = src[ip + k];     // exact bytes next to the end of either buffer
+                ip += lit;
+                op += lit;
+            }
+            if (ip >= iend) break;                                  // :146
+            if (iend - ip < 2u) { res = kErrCorrupted; break; }     // :149
+            const uint32_t offset = ld16(src + ip);                 // :150
+            ip += 2;
+            if (offset == 0) { res = kErrCorrupted; break; }        // :154
+            uint32_t ml = token & 15u;                              // :157
+            if (ml == 15u) {                                        // :160-168
+                bool bad = false;
+                for (;;) {
+                    if (ip >= iend) { bad = true; break; }          // :162
+                    const uint32_t s = src[ip];
+                    ip += 1;
+                    ml += s;
+                    if (ml > 0xFFFF0000u) ml = 0xFFFF0000u;
+                    if (s != 255u) break;
+                }
+                if (bad) { res = kErrCorrupted; break; }
+            }
+            ml += kMinMatch;                                        // :171
+            if (ml > oend - op) { res = kErrOutputTooSmall; break; }   // :174
+            if (offset > op) { res = kErrCorrupted; break; }        // :181-186 (no dict) / :231
+            const uint8_t *m = dst + (op - offset);
+            uint8_t *o = dst + op;
+            uint32_t k = 0;
+            if (offset >= 16u) {                                    // chunks never read what they are about to write
+                while (k < ml && op + k + 16u <= oend) { st128(o + k, ld128(m + k)); k += 16u; }
+            } else if (offset >= 8u) {
+                while (k < ml && op + k + 8u <= oend) { const uint64_t v = ld64u(m + k); __builtin_memcpy(o + k, &v, 8); k += 8u; }
+            }
+            for (; k < ml; k++) o[k] = m[k];                        // :238-240 byte-serial (overlap, or next to the end)
+            op += ml;
+            have_w = ip + 16u <= iend;
+            if (have_w) w = ld128(src + ip);
+        }
+        if (res == 0) res = (int64_t)op;                            // :250
+    }
+    d_result[blk] = res;
+}
+
 }  // namespace zlz4
 
 extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
                                            const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                                            const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks) {
     if (nblocks == 0) return 0;
+    // large batches: one lane per block (64 blocks per wavefront); small batches: one wavefront per block
+    static const uint32_t lane_min = [] { const char *e = getenv("ZLZ4_DECOMP_LANE_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
+    if (nblocks >= lane_min) {
+        // the kernel is latency-bound: with few blocks use fewer lanes per wavefront so that ~8192 wavefronts exist
+        static const uint32_t lanes_env = [] { const char *e = getenv("ZLZ4_DECOMP_LANES"); return e ? (uint32_t)atoi(e) : 0u; }();
+        // measured on MI355X (65 536 blocks): 16 or 32 active lanes per wavefront are ~5 % faster than 64
+        uint32_t lanes = nblocks >= 524288u ? 64u : (nblocks >= 262144u ? 32u : 16u);
+        if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
+        hipLaunchKernelGGL(zlz4::k_decompress_lane, dim3((nblocks + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off,
+                           d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+        return hipGetLastError() == hipSuccess ? 0 : -7;
+    }
     const uint32_t waves_per_wg = 4;
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
     hipLaunchKernelGGL(zlz4::k_decompress_safe<true>, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,

@@ -331,7 +331,7 @@ __global__ void k_dframe_plan(const uint32_t *__restrict__ data_len, const uint3
             }
         }
         out_off[i] = pos;
-        out_cap[i] = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
+        out_cap[i] = (uint32_t)sz;      // exact: the block decoders may chunk-write up to their capacity, never beyond
         pos += sz;
     }
     if (!err) err = walk_err;
