@@ -22,7 +22,6 @@ extern "C" int zlz4_launch_compress_hc(hipStream_t, const uint8_t *, const uint6
                                        const uint64_t *, const uint32_t *, int64_t *, uint32_t, uint32_t, int32_t,
                                        void *, size_t);
 extern "C" size_t zlz4_hc_workspace_bytes(uint32_t nblocks, uint32_t max_in_len);
-extern "C" int zlz4_launch_frame_helpers_init(void);
 
 namespace {
 
@@ -55,8 +54,6 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
-
-struct BlockDesc { uint64_t in_off; uint32_t in_len; uint64_t out_off; uint32_t out_cap; };
 
 enum class Op { Fast, Hc, Decompress };
 

@@ -171,10 +171,15 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 STAMP(1);
                 STAMP_COUNT(8);
                 uint32_t old = 0, rb = 0;
-                if (wr) {
-                    old = table[h];                                     // :342
-                    table[h] = (T)pos;                                  // :350 (speculative)
-                }
+                if (wr) old = table[h];                                 // :342
+                // pre-window candidates: the old table value passes `match > 0`, `match < ip` (always) and
+                // the distance test (:345-347); its bytes are gathered once for the whole window.  The gather is
+                // issued right away so that its latency overlaps the speculative put / read-back below.
+                const bool old_ok = wr && old > 0 && (old + kMaxDist >= pos);
+                u32x4 cold = {0, 0, 0, 0};
+                if (old_ok) cold = ld128(src + old);
+                STAMP(3);
+                if (wr) table[h] = (T)pos;                              // :350 (speculative)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (wr) rb = table[h];
                 uint64_t losers = ballot(wr && rb != (uint32_t)(T)pos);
@@ -187,12 +192,6 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     losers &= ~same;
                 }
                 STAMP(2);
-                // pre-window candidates: the old table value passes `match > 0`, `match < ip` (always) and
-                // the distance test (:345-347); its bytes are gathered once for the whole window
-                const bool old_ok = wr && old > 0 && (old + kMaxDist >= pos);
-                u32x4 cold = {0, 0, 0, 0};
-                if (old_ok) cold = ld128(src + old);
-                STAMP(3);
 
                 // What a probe at lane i finds if its table slot still holds the pre-window value: validity
                 // (:345-348), the first 12 bytes of forward extension (:401-413) and the offset.  For a lane

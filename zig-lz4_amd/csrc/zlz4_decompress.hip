@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
                 const uint32_t tok = w.x & 0xFFu;
                 const uint32_t lit = tok >> 4, mlc = tok & 15u;
                 // fast path: no length extension, header + literals inside the 16 bytes, room for chunk stores
-                if (lit <= 13u && mlc != 15u && op + lit + 48u <= oend) {
+                if (lit <= 13u && mlc != 15u && (uint64_t)op + lit + 48u <= oend) {
                     // (ip + 16 <= iend holds, so the literals fit (:136) and the offset is present (:146, :149);
                     //  op + lit + 48 <= oend covers :137 and :174 and keeps every chunk store inside dst)
                     const uint32_t oi = 1u + lit;                   // byte index of the offset inside w
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
                     const uint32_t offset = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 0xFFFFu;   // :150
                     const uint32_t nip = ip + 3u + lit;
                     u32x4 wn = {0, 0, 0, 0};
-                    const bool have_n = nip + 16u <= iend;
+                    const bool have_n = (uint64_t)nip + 16u <= iend;
                     if (have_n) wn = ld128(src + nip);              // next header: in flight during the copies
                     u32x4 ls;                                       // literals = bytes 1..lit of w (:140), chunk store
                     ls.x = (w.x >> 8) | (w.y << 24); ls.y = (w.y >> 8) | (w.z << 24);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
                 if (lit > iend - ip) { res = kErrCorrupted; break; }        // :136
                 if (lit > oend - op) { res = kErrOutputTooSmall; break; }   // :137
                 uint32_t k = 0;                                     // :140
-                while (k < lit && ip + k + 16u <= iend && op + k + 16u <= oend) {
+                while (k < lit && (uint64_t)ip + k + 16u <= iend && (uint64_t)op + k + 16u <= oend) {
                     st128(dst + op + k, ld128(src + ip + k));
                     k += 16u;
                 }
@@ -286,13 +286,13 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
             uint8_t *o = dst + op;
             uint32_t k = 0;
             if (offset >= 16u) {                                    // chunks never read what they are about to write
-                while (k < ml && op + k + 16u <= oend) { st128(o + k, ld128(m + k)); k += 16u; }
+                while (k < ml && (uint64_t)op + k + 16u <= oend) { st128(o + k, ld128(m + k)); k += 16u; }
             } else if (offset >= 8u) {
-                while (k < ml && op + k + 8u <= oend) { const uint64_t v = ld64u(m + k); __builtin_memcpy(o + k, &v, 8); k += 8u; }
+                while (k < ml && (uint64_t)op + k + 8u <= oend) { const uint64_t v = ld64u(m + k); __builtin_memcpy(o + k, &v, 8); k += 8u; }
             }
             for (; k < ml; k++) o[k] = m[k];                        // :238-240 byte-serial (overlap, or next to the end)
             op += ml;
-            have_w = ip + 16u <= iend;
+            have_w = (uint64_t)ip + 16u <= iend;
             if (have_w) w = ld128(src + ip);
         }
         if (res == 0) res = (int64_t)op;                            // :250
