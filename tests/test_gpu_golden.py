@@ -95,3 +95,32 @@ def test_large_blocks_4mib_round_trip(zl, gpu):
     """config 5 block size: 4 MiB blocks use the 32-bit table variants of both compressors."""
     _roundtrip(zl, gpu, "text", 24, 4 << 20)
     _roundtrip(zl, gpu, "text", 6, 4 << 20, hc_level=9)
+
+
+def test_frame_device_api_many_blocks(zl, gpu):
+    """lz4f on a device-resident 1.2 GiB buffer with 64 KiB blocks (18 500 blocks + a short last one): the frame
+    decoder then runs the one-lane-per-block kernel with exact per-block capacities; checksums on."""
+    import ctypes as C
+    import bench
+    nblocks, block = 18500, 65536
+    inp = bench.make_device_blocks("text", nblocks, block, gpu, seed=5).reshape(-1)
+    inp = torch.cat([inp, inp[:12345]])
+    n = inp.numel()
+    prefs = zl.Prefs()
+    prefs.block_size_id = 4
+    prefs.block_checksum = 1
+    prefs.content_checksum = 1
+    bound = zl.lz4f.compressFrameBound(n, prefs)
+    frame = torch.empty(bound, dtype=torch.uint8, device=gpu)
+    out = torch.full((n + 64,), 0x5A, dtype=torch.uint8, device=gpu)
+    L = zl.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fs = L.zlz4f_compress_frame_device(st, C.c_void_p(inp.data_ptr()), n, C.c_void_p(frame.data_ptr()), bound, C.byref(prefs))
+    assert fs > 0, zl.error_name(fs)
+    r = L.zlz4f_decompress_frame_device(st, C.c_void_p(frame.data_ptr()), fs, C.c_void_p(out.data_ptr()), n)
+    assert r == n, zl.error_name(r)
+    assert torch.equal(out[:n], inp) and bool((out[n:] == 0x5A).all())
+    # corrupt one payload byte in the middle of the frame: block checksum must catch it (src/lz4f.zig:594-598)
+    frame[fs // 2] ^= 0x40
+    r = L.zlz4f_decompress_frame_device(st, C.c_void_p(frame.data_ptr()), fs, C.c_void_p(out.data_ptr()), n)
+    assert zl.error_name(r) == "BlockChecksumInvalid"
