@@ -90,6 +90,26 @@ int64_t zlz4_compress_hc(const uint8_t *src, size_t src_len, uint8_t *dst, size_
 /* replaces lz4.decompressSafe, src/lz4.zig:257-259 (decompressGeneric :89-251, no dict) */
 int64_t zlz4_decompress_safe(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap);
 
+/* replaces lz4.decompressSafePartial, src/lz4.zig:619-621: decompressGeneric with targetOutputSize as the
+ * output limit (:99, :109) -- i.e. OutputTooSmall as soon as a sequence would pass `target_output_size`. */
+int64_t zlz4_decompress_safe_partial(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                                     size_t target_output_size);
+
+/* replaces lz4.sizeofState, src/lz4.zig:524-526 (= @sizeOf(HashTable) = 16384) */
+size_t  zlz4_sizeof_state(void);
+
+/* replaces lz4.compressFastExtState, src/lz4.zig:531-546: InvalidState when the caller's state buffer is
+ * smaller than sizeofState(), otherwise the output of compressFast (the device keeps its tables in LDS;
+ * the state buffer is only validated, never written). */
+int64_t zlz4_compress_fast_ext_state(void *state, size_t state_len, const uint8_t *src, size_t src_len,
+                                     uint8_t *dst, size_t dst_cap, uint32_t acceleration);
+
+/* replaces lz4.compressDestSize, src/lz4.zig:551-616: largest prefix of src whose compressDefault output fits
+ * dst (the reference's binary search, same probes in the same order).  *src_size: in = bytes available,
+ * out = bytes consumed.  Returns the compressed size.  dst holds the compression of the consumed prefix (the
+ * reference leaves the output of its LAST probe there, which is not always that one). */
+int64_t zlz4_compress_dest_size(const uint8_t *src, uint8_t *dst, size_t dst_cap, size_t *src_size);
+
 /* ======================================================================
  * 2. Batch entry points, DEVICE pointers -- the data-parallel hot path.
  *    Block i reads  d_in  + d_in_off[i]  (d_in_len[i] bytes) and writes

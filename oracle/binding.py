@@ -51,6 +51,13 @@ def lib():
         L.zo_compress_fast.argtypes = [u8p, sz, u8p, sz, C.c_uint32]
         L.zo_compress_hc.restype = i64
         L.zo_compress_hc.argtypes = [u8p, sz, u8p, sz, C.c_int32]
+        L.zo_sizeof_state.restype = sz
+        L.zo_compress_fast_ext_state.restype = i64
+        L.zo_compress_fast_ext_state.argtypes = [sz, u8p, sz, u8p, sz, C.c_uint32]
+        L.zo_compress_dest_size.restype = i64
+        L.zo_compress_dest_size.argtypes = [u8p, u8p, sz, C.POINTER(C.c_size_t)]
+        L.zo_decompress_safe_partial.restype = i64
+        L.zo_decompress_safe_partial.argtypes = [u8p, sz, u8p, sz, sz]
         L.zo_xxh32.restype = C.c_uint32
         L.zo_xxh32.argtypes = [u8p, sz, C.c_uint32]
         L.zo_compress_frame_bound.restype = sz
@@ -104,6 +111,30 @@ def compress_hc(src, level, cap=None):
 
 def decompress_safe(src, cap):
     return _call(lib().zo_decompress_safe, src, cap)
+
+
+def compress_fast_ext_state(state_len, src, accel, cap=None):
+    cap = compress_bound(len(src)) if cap is None else cap
+    s, n = _buf(src)
+    d = (C.c_uint8 * max(1, cap))()
+    r = lib().zo_compress_fast_ext_state(state_len, C.addressof(s), n, C.addressof(d), cap, accel)
+    return r if r < 0 else bytes(d[:r])
+
+
+def compress_dest_size(src, cap):
+    """-> (returned size or error, consumed source bytes)"""
+    s, n = _buf(src)
+    d = (C.c_uint8 * max(1, cap))()
+    ss = C.c_size_t(n)
+    r = lib().zo_compress_dest_size(C.addressof(s), C.addressof(d), cap, C.byref(ss))
+    return r, ss.value
+
+
+def decompress_safe_partial(src, cap, target):
+    s, n = _buf(src)
+    d = (C.c_uint8 * max(1, cap))()
+    r = lib().zo_decompress_safe_partial(C.addressof(s), n, C.addressof(d), cap, target)
+    return r if r < 0 else bytes(d[:r])
 
 
 def xxh32(data, seed=0):

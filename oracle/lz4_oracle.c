@@ -55,12 +55,12 @@ size_t zo_compress_bound(size_t inputSize) {
 /* ===================== decompression, src/lz4.zig:89-251 ===================== */
 /* decompressSafe = decompressGeneric(src, dst, dst.len, null, null) (:257-259):
  * lowPrefix == dst.ptr, dictEnd == null. */
-int64_t zo_decompress_safe(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t dstLen) {
+static int64_t decompress_generic(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t dstLen, size_t targetOutputSize) {
     if (srcLen == 0) return 0;                      /* :97 */
     if (dstLen == 0) return 0;                      /* :98 */
-    /* :99 targetOutputSize == dst.len, never greater */
+    if (targetOutputSize > dstLen) return ZO_ERR_OUTPUT_TOO_SMALL;   /* :99 */
     size_t ip = 0, op = 0;                          /* :106-107 */
-    const size_t iend = srcLen, oend = dstLen;      /* :108-109 */
+    const size_t iend = srcLen, oend = targetOutputSize;   /* :108-109 */
 
     for (;;) {                                      /* :111 */
         if (ip >= iend) break;                      /* :113 */
@@ -113,6 +113,15 @@ int64_t zo_decompress_safe(const uint8_t *src, size_t srcLen, uint8_t *dst, size
         }
     }
     return (int64_t)op;                             /* :250 */
+}
+
+/* src/lz4.zig:257-259 */
+int64_t zo_decompress_safe(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    return decompress_generic(src, n, dst, cap, cap);
+}
+/* src/lz4.zig:619-621 */
+int64_t zo_decompress_safe_partial(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t targetOutputSize) {
+    return decompress_generic(src, n, dst, cap, targetOutputSize);
 }
 
 /* ===================== fast compression, src/lz4.zig:263-519 ===================== */
@@ -291,6 +300,59 @@ int64_t zo_compress_fast(const uint8_t *src, size_t srcSize, uint8_t *dst, size_
 /* src/lz4.zig:283-285 */
 int64_t zo_compress_default(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
     return zo_compress_fast(src, n, dst, cap, 1);
+}
+
+/* src/lz4.zig:524-526: @sizeOf(HashTable) */
+size_t zo_sizeof_state(void) { return LZ4_HASH_SIZE_U32 * sizeof(uint32_t); }
+
+/* src/lz4.zig:531-546; compressFastWithHashTable (:624-740) is a verbatim copy of compressFast's loop */
+int64_t zo_compress_fast_ext_state(size_t stateLen, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, uint32_t accel) {
+    if (stateLen < zo_sizeof_state()) return ZO_ERR_INVALID_STATE;      /* :532 */
+    return zo_compress_fast(src, n, dst, cap, accel);                  /* :534-545 */
+}
+
+/* src/lz4.zig:551-616.  NOTE: like the reference, `dst` holds the output of the LAST attempt, which is not
+ * necessarily the best one; only the returned size and *srcSizePtr are specified here. */
+int64_t zo_compress_dest_size(const uint8_t *src, uint8_t *dst, size_t dstLen, size_t *srcSizePtr) {
+    const size_t maxSrcSize = *srcSizePtr;
+    if (maxSrcSize == 0) { *srcSizePtr = 0; return 0; }                /* :553-556 */
+    const size_t maxCompressed = zo_compress_bound(maxSrcSize);        /* :559 */
+    if (dstLen >= maxCompressed) {                                     /* :560-564 */
+        const int64_t r = zo_compress_default(src, maxSrcSize, dst, dstLen);
+        if (r < 0) return r;
+        *srcSizePtr = maxSrcSize;
+        return r;
+    }
+    size_t low = 1, high = maxSrcSize, bestSize = 0, bestCompressedSize = 0;   /* :567-570 */
+    if (dstLen <= maxSrcSize) {                                        /* :573-586 */
+        const size_t estimate = dstLen < maxSrcSize ? dstLen : maxSrcSize;
+        const int64_t r = zo_compress_default(src, estimate, dst, dstLen);
+        if (r >= 0) {
+            if ((size_t)r <= dstLen) { bestSize = estimate; bestCompressedSize = (size_t)r; low = estimate + 1; }
+            else high = estimate - 1;
+        } else {
+            high = estimate - 1;
+        }
+    }
+    while (low <= high) {                                              /* :589-612 */
+        const size_t mid = low + (high - low) / 2;
+        if (mid == 0 || mid > maxSrcSize) break;
+        const int64_t r = zo_compress_default(src, mid, dst, dstLen);
+        if (r >= 0) {
+            if ((size_t)r <= dstLen) {
+                bestSize = mid; bestCompressedSize = (size_t)r;
+                if (mid == maxSrcSize) break;
+                low = mid + 1;
+            } else {
+                high = mid - 1;
+            }
+        } else {
+            high = mid - 1;
+        }
+        if (low > maxSrcSize) break;
+    }
+    *srcSizePtr = bestSize;                                            /* :614-615 */
+    return (int64_t)bestCompressedSize;
 }
 
 /* ===================== HC, src/lz4hc.zig ===================== */

@@ -75,6 +75,13 @@ int64_t zo_compress_default(const uint8_t *src, size_t n, uint8_t *dst,
                             size_t cap);                               /* lz4.zig:283-285 */
 int64_t zo_decompress_safe(const uint8_t *src, size_t n, uint8_t *dst,
                            size_t cap);                                /* lz4.zig:257-259 */
+size_t  zo_sizeof_state(void);                                         /* lz4.zig:524-526 */
+int64_t zo_compress_fast_ext_state(size_t state_len, const uint8_t *src, size_t n, uint8_t *dst,
+                                   size_t cap, uint32_t accel);        /* lz4.zig:531-546 */
+int64_t zo_compress_dest_size(const uint8_t *src, uint8_t *dst, size_t cap,
+                              size_t *src_size_inout);                 /* lz4.zig:551-616 */
+int64_t zo_decompress_safe_partial(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                                   size_t target_output_size);         /* lz4.zig:619-621 */
 int64_t zo_compress_hc(const uint8_t *src, size_t n, uint8_t *dst,
                        size_t cap, int32_t level);                     /* lz4hc.zig:1440-1453 */
 

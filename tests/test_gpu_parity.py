@@ -147,3 +147,37 @@ def test_single_buffer_entry_points(zl, oracle, gpu):
     with pytest.raises(zl.Lz4Error) as e:
         zl.compressDefault(b"A" * 100, dst_cap=3)
     assert e.value.name == "OutputTooSmall"
+
+
+def test_rank4_entry_points(zl, oracle, gpu):
+    """compressFastExtState, compressDestSize, decompressSafePartial, sizeofState."""
+    assert zl.sizeofState() == 16384
+    b = bytes(dg.text_bytes(50000, 1))
+    assert zl.compressFastExtState(16384, b, 1) == oracle.compress_fast_ext_state(16384, b, 1)
+    assert zl.compressFastExtState(20000, b, 9) == oracle.compress_fast(b, 9)
+    with pytest.raises(zl.Lz4Error) as e:
+        zl.compressFastExtState(16383, b, 1)
+    assert e.value.name == "InvalidState" and oracle.compress_fast_ext_state(16383, b, 1) == -5
+    for data in (b, bytes(dg.random_bytes(30000, 2)), b"\0" * 40000, b[:100], b""):
+        for cap in (0, 1, 5, 13, 100, 1000, 10000, len(data), len(data) + 200, 70000):
+            want_r, want_consumed = oracle.compress_dest_size(data, cap)
+            out, consumed = zl.compressDestSize(data, cap)
+            assert (len(out), consumed) == (want_r, want_consumed), (len(data), cap)
+            if consumed:
+                assert out == oracle.compress_default(data[:consumed], cap=cap), (len(data), cap)
+                assert zl.decompressSafe(out, consumed) == data[:consumed]
+    c = oracle.compress_default(b)
+    for cap, target in ((50000, 50000), (50000, 100), (100, 200), (50000, 0), (60000, 55000), (0, 0), (50000, 49999)):
+        want = oracle.decompress_safe_partial(c, cap, target)
+        try:
+            got = zl.decompressSafePartial(c, cap, target)
+        except zl.Lz4Error as e:
+            got = e.code
+        assert got == want, (cap, target)
+    for stream in (b"\x00", b"\x10A", b"\x00\x01\x00", b"\x0f\x01\x00", b"\xf0", b"\x00\x00\x00"):
+        want = oracle.decompress_safe_partial(stream, 10, 0)
+        try:
+            got = zl.decompressSafePartial(stream, 10, 0)
+        except zl.Lz4Error as e:
+            got = e.code
+        assert got == want, stream

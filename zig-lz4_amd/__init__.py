@@ -59,6 +59,10 @@ SYMBOLS = {
     "zlz4_compress_fast": (_I64, [_VP, _SZ, _VP, _SZ, _U32]),
     "zlz4_compress_hc": (_I64, [_VP, _SZ, _VP, _SZ, _I32]),
     "zlz4_decompress_safe": (_I64, [_VP, _SZ, _VP, _SZ]),
+    "zlz4_decompress_safe_partial": (_I64, [_VP, _SZ, _VP, _SZ, _SZ]),
+    "zlz4_sizeof_state": (_SZ, []),
+    "zlz4_compress_fast_ext_state": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ, _U32]),
+    "zlz4_compress_dest_size": (_I64, [_VP, _VP, _SZ, C.POINTER(C.c_size_t)]),
     "zlz4_batch_compress_fast": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _U32, _U32]),
     "zlz4_batch_decompress_safe": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32]),
     "zlz4_batch_compress_hc_workspace": (_SZ, [_U32, _U32]),
@@ -155,6 +159,35 @@ def compressHC(src, compression_level, dst_cap=None):
 def decompressSafe(src, dst_cap):
     """lz4.decompressSafe(src, dst), src/lz4.zig:257-259; dst_cap == dst.len."""
     return _run(lib().zlz4_decompress_safe, src, dst_cap)
+
+
+def decompressSafePartial(src, dst_cap, target_output_size):
+    """lz4.decompressSafePartial(src, dst, targetOutputSize), src/lz4.zig:619-621."""
+    return _run(lib().zlz4_decompress_safe_partial, src, dst_cap, target_output_size)
+
+
+def sizeofState():
+    """lz4.sizeofState, src/lz4.zig:524-526."""
+    return lib().zlz4_sizeof_state()
+
+
+def compressFastExtState(state_len, src, acceleration, dst_cap=None):
+    """lz4.compressFastExtState(state, src, dst, acceleration), src/lz4.zig:531-546 (state given by its length)."""
+    cap = compressBound(len(src)) if dst_cap is None else dst_cap
+    s, n = _in(src)
+    st = (C.c_uint8 * max(1, state_len))()
+    d = (C.c_uint8 * max(1, cap))()
+    r = _check(lib().zlz4_compress_fast_ext_state(C.addressof(st), state_len, C.addressof(s), n, C.addressof(d), cap, acceleration))
+    return bytes(d[:r])
+
+
+def compressDestSize(src, dst_cap):
+    """lz4.compressDestSize(src, dst, &srcSize), src/lz4.zig:551-616 -> (compressed bytes, consumed source bytes)."""
+    s, n = _in(src)
+    d = (C.c_uint8 * max(1, dst_cap))()
+    ss = C.c_size_t(n)
+    r = _check(lib().zlz4_compress_dest_size(C.addressof(s), C.addressof(d), dst_cap, C.byref(ss)))
+    return bytes(d[:r]), ss.value
 
 
 class lz4f:

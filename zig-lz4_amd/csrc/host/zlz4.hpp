@@ -40,6 +40,19 @@ inline Result compressFast(const std::uint8_t *src, std::size_t n, std::uint8_t 
 inline Result decompressSafe(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap) {
     return wrap(zlz4_decompress_safe(src, n, dst, cap));
 }
+// lz4.decompressSafePartial, src/lz4.zig:619-621
+inline Result decompressSafePartial(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap, std::size_t target) {
+    return wrap(zlz4_decompress_safe_partial(src, n, dst, cap, target));
+}
+// lz4.sizeofState / compressFastExtState / compressDestSize, src/lz4.zig:524-616
+inline std::size_t sizeofState() { return zlz4_sizeof_state(); }
+inline Result compressFastExtState(void *state, std::size_t state_len, const std::uint8_t *src, std::size_t n,
+                                   std::uint8_t *dst, std::size_t cap, std::uint32_t accel) {
+    return wrap(zlz4_compress_fast_ext_state(state, state_len, src, n, dst, cap, accel));
+}
+inline Result compressDestSize(const std::uint8_t *src, std::uint8_t *dst, std::size_t cap, std::size_t *src_size) {
+    return wrap(zlz4_compress_dest_size(src, dst, cap, src_size));
+}
 // lz4hc.compressHC, src/lz4hc.zig:1440-1453
 inline Result compressHC(const std::uint8_t *src, std::size_t n, std::uint8_t *dst, std::size_t cap, std::int32_t level) {
     return wrap(zlz4_compress_hc(src, n, dst, cap, level));

@@ -184,6 +184,127 @@ int64_t zlz4_decompress_safe(const uint8_t *src, size_t n, uint8_t *dst, size_t 
     return run_single(Op::Decompress, src, n, dst, cap, 0, 0);
 }
 
+int64_t zlz4_decompress_safe_partial(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t target) {
+    if (n == 0) return 0;                                           // src/lz4.zig:97
+    if (cap == 0) return 0;                                         // :98
+    if (target > cap) return ZLZ4_ERR_OUTPUT_TOO_SMALL;             // :99
+    if (target > 0) return run_single(Op::Decompress, src, n, dst, target, 0, 0);   // oend = targetOutputSize (:109)
+    // target == 0 with a non-empty dst: no byte can be produced, the result is decided by the first sequence
+    // header alone (:111-174) -- nothing to run on the device
+    size_t ip = 0;
+    const uint8_t token = src[ip++];
+    size_t lit = token >> 4;
+    if (lit == 15) {
+        for (;;) {
+            if (ip >= n) return ZLZ4_ERR_CORRUPTED_DATA;            // :125
+            const uint8_t s = src[ip++];
+            lit += s;
+            if (s != 255) break;
+        }
+    }
+    if (lit > 0) {
+        if (ip + lit > n) return ZLZ4_ERR_CORRUPTED_DATA;           // :136
+        return ZLZ4_ERR_OUTPUT_TOO_SMALL;                           // :137 (op + lit > 0)
+    }
+    if (ip >= n) return 0;                                          // :146
+    if (ip + 2 > n) return ZLZ4_ERR_CORRUPTED_DATA;                 // :149
+    if ((src[ip] | (src[ip + 1] << 8)) == 0) return ZLZ4_ERR_CORRUPTED_DATA;   // :154
+    ip += 2;
+    if ((token & 15) == 15) {
+        for (;;) {
+            if (ip >= n) return ZLZ4_ERR_CORRUPTED_DATA;            // :162
+            if (src[ip++] != 255) break;
+        }
+    }
+    return ZLZ4_ERR_OUTPUT_TOO_SMALL;                               // :174 (op + matchLength > 0)
+}
+
+size_t zlz4_sizeof_state(void) { return 4096 * sizeof(uint32_t); }  // src/lz4.zig:524-526, :263-265
+
+int64_t zlz4_compress_fast_ext_state(void *state, size_t state_len, const uint8_t *src, size_t n, uint8_t *dst,
+                                     size_t cap, uint32_t accel) {
+    (void)state;
+    if (state_len < zlz4_sizeof_state()) return ZLZ4_ERR_INVALID_STATE;   // src/lz4.zig:532
+    return zlz4_compress_fast(src, n, dst, cap, accel);                  // :534-545
+}
+
+int64_t zlz4_compress_dest_size(const uint8_t *src, uint8_t *dst, size_t cap, size_t *src_size) {
+    const size_t max_src = *src_size;
+    if (max_src == 0) { *src_size = 0; return 0; }                  // src/lz4.zig:553-556
+    if (cap >= zlz4_compress_bound(max_src)) {                      // :559-564
+        const int64_t r = zlz4_compress_default(src, max_src, dst, cap);
+        if (r < 0) return r;
+        *src_size = max_src;
+        return r;
+    }
+    if (!device_ok()) return ZLZ4_ERR_DEVICE;
+    if (max_src > ZLZ4_MAX_INPUT_SIZE) {
+        // probes larger than the input limit fail with InputTooLarge in the reference (:594-607 -> `high = mid - 1`);
+        // the search below never needs more than this many source bytes on the device
+    }
+    const size_t stage = max_src > ZLZ4_MAX_INPUT_SIZE ? (size_t)ZLZ4_MAX_INPUT_SIZE : max_src;
+    const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+    DevBuf d_in(stage), d_out(cap32), d_meta(64);
+    if (!d_in.p || !d_out.p || !d_meta.p) return ZLZ4_ERR_ALLOCATION_FAILED;
+    if (hipMemcpy(d_in.p, src, stage, hipMemcpyHostToDevice) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    struct Meta { uint64_t in_off; uint64_t out_off; int64_t result; uint32_t in_len; uint32_t out_cap; };
+    auto *dm = d_meta.as<uint8_t>();
+    // one probe = compressDefault(src[0..len], dst) on the device; the input stays resident
+    auto probe = [&](size_t len) -> int64_t {
+        if (len > ZLZ4_MAX_INPUT_SIZE) return ZLZ4_ERR_INPUT_TOO_LARGE;        // src/lz4.zig:296
+        if (len == 0) return 0;                                                // :299
+        Meta m; m.in_off = 0; m.out_off = 0; m.result = 0; m.in_len = (uint32_t)len; m.out_cap = cap32;
+        if (hipMemcpy(d_meta.p, &m, sizeof m, hipMemcpyHostToDevice) != hipSuccess) return ZLZ4_ERR_DEVICE;
+        const int rc = zlz4_launch_compress_fast(nullptr, d_in.as<uint8_t>(),
+                                                 reinterpret_cast<const uint64_t *>(dm + offsetof(Meta, in_off)),
+                                                 reinterpret_cast<const uint32_t *>(dm + offsetof(Meta, in_len)),
+                                                 d_out.as<uint8_t>(),
+                                                 reinterpret_cast<const uint64_t *>(dm + offsetof(Meta, out_off)),
+                                                 reinterpret_cast<const uint32_t *>(dm + offsetof(Meta, out_cap)),
+                                                 reinterpret_cast<int64_t *>(dm + offsetof(Meta, result)), 1, (uint32_t)len, 1);
+        if (rc != 0) return rc;
+        int64_t r = 0;
+        if (hipMemcpy(&r, dm + offsetof(Meta, result), sizeof r, hipMemcpyDeviceToHost) != hipSuccess) return ZLZ4_ERR_DEVICE;
+        return r;
+    };
+    size_t low = 1, high = max_src, best = 0, best_c = 0, last_ok_len = (size_t)-1;     // :567-570
+    auto attempt = [&](size_t len, bool &fits) -> int64_t {
+        const int64_t r = probe(len);
+        fits = r >= 0 && (size_t)r <= cap;
+        last_ok_len = r >= 0 ? len : (size_t)-1;      // a failed probe leaves a partial stream in d_out
+        return r;
+    };
+    if (cap <= max_src) {                                           // :573-586
+        const size_t estimate = cap < max_src ? cap : max_src;
+        bool fits;
+        const int64_t r = attempt(estimate, fits);
+        if (r == ZLZ4_ERR_DEVICE) return r;
+        if (fits) { best = estimate; best_c = (size_t)r; low = estimate + 1; }
+        else high = estimate - 1;
+    }
+    while (low <= high) {                                           // :589-612
+        const size_t mid = low + (high - low) / 2;
+        if (mid == 0 || mid > max_src) break;
+        bool fits;
+        const int64_t r = attempt(mid, fits);
+        if (r == ZLZ4_ERR_DEVICE) return r;
+        if (fits) {
+            best = mid; best_c = (size_t)r;
+            if (mid == max_src) break;
+            low = mid + 1;
+        } else {
+            high = mid - 1;
+        }
+        if (low > max_src) break;
+    }
+    if (best > 0) {
+        if (last_ok_len != best) { bool f; if (attempt(best, f) < 0) return ZLZ4_ERR_DEVICE; }   // put the best one into d_out
+        if (hipMemcpy(dst, d_out.p, best_c, hipMemcpyDeviceToHost) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    }
+    *src_size = best;                                               // :614-615
+    return (int64_t)best_c;
+}
+
 // ---------------------------------------------------------------- batch, device pointers
 int32_t zlz4_batch_compress_fast(void *stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                  uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,

@@ -14,6 +14,10 @@ extern "c" fn zlz4_compress_default(src: [*]const u8, src_len: usize, dst: [*]u8
 extern "c" fn zlz4_compress_fast(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, acceleration: u32) i64;
 extern "c" fn zlz4_compress_hc(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, level: i32) i64;
 extern "c" fn zlz4_decompress_safe(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize) i64;
+extern "c" fn zlz4_decompress_safe_partial(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, target: usize) i64;
+extern "c" fn zlz4_sizeof_state() usize;
+extern "c" fn zlz4_compress_fast_ext_state(state: [*]u8, state_len: usize, src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, acceleration: u32) i64;
+extern "c" fn zlz4_compress_dest_size(src: [*]const u8, dst: [*]u8, dst_cap: usize, src_size: *usize) i64;
 
 pub const CPrefs = extern struct {
     block_size_id: u32 = 0,
@@ -74,6 +78,22 @@ pub fn compressFast(src: []const u8, dst: []u8, acceleration: u32) Error!usize {
 }
 pub fn decompressSafe(src: []const u8, dst: []u8) Error!usize {
     return mapBlock(zlz4_decompress_safe(src.ptr, src.len, dst.ptr, dst.len));
+}
+/// reference src/lz4.zig:619-621
+pub fn decompressSafePartial(src: []const u8, dst: []u8, targetOutputSize: usize) Error!usize {
+    return mapBlock(zlz4_decompress_safe_partial(src.ptr, src.len, dst.ptr, dst.len, targetOutputSize));
+}
+/// reference src/lz4.zig:524-526
+pub fn sizeofState() usize {
+    return zlz4_sizeof_state();
+}
+/// reference src/lz4.zig:531-546
+pub fn compressFastExtState(state: []u8, src: []const u8, dst: []u8, acceleration: u32) Error!usize {
+    return mapBlock(zlz4_compress_fast_ext_state(state.ptr, state.len, src.ptr, src.len, dst.ptr, dst.len, acceleration));
+}
+/// reference src/lz4.zig:551-616 (srcSizePtr: in = available, out = consumed)
+pub fn compressDestSize(src: []const u8, dst: []u8, srcSizePtr: *usize) Error!usize {
+    return mapBlock(zlz4_compress_dest_size(src.ptr, dst.ptr, dst.len, srcSizePtr));
 }
 pub fn compressHC(src: []const u8, dst: []u8, compressionLevel: i32) Error!usize {
     return mapBlock(zlz4_compress_hc(src.ptr, src.len, dst.ptr, dst.len, compressionLevel));
