@@ -177,8 +177,8 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
     const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks) {
-    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim.x = active lanes per wavefront
-    if (blk >= nblocks) return;
+  // grid-stride over blocks: the launcher may cap the number of concurrently decoded blocks
+  for (uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x; blk < nblocks; blk += gridDim.x * blockDim.x) {   // blockDim.x = active lanes per wavefront
     const uint8_t *src = d_in + d_in_off[blk];
     uint8_t *dst = d_out + d_out_off[blk];
     const uint32_t iend = d_in_len[blk], oend = d_out_cap[blk];
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
         if (res == 0) res = (int64_t)op;                            // :250
     }
     d_result[blk] = res;
+  }
 }
 
 }  // namespace zlz4
@@ -314,7 +315,10 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
         // measured on MI355X (65 536 blocks): 16 or 32 active lanes per wavefront are ~5 % faster than 64
         uint32_t lanes = nblocks >= 524288u ? 64u : (nblocks >= 262144u ? 32u : 16u);
         if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
-        hipLaunchKernelGGL(zlz4::k_decompress_lane, dim3((nblocks + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off,
+        static const uint32_t max_lanes = [] { const char *e = getenv("ZLZ4_DECOMP_MAXLANES"); return e ? (uint32_t)atoll(e) : 0u; }();
+        uint32_t grid = (nblocks + lanes - 1u) / lanes;
+        if (max_lanes && (uint64_t)grid * lanes > max_lanes) grid = (max_lanes + lanes - 1u) / lanes;
+        hipLaunchKernelGGL(zlz4::k_decompress_lane, dim3(grid), dim3(lanes), 0, stream, d_in, d_in_off,
                            d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
         return hipGetLastError() == hipSuccess ? 0 : -7;
     }
