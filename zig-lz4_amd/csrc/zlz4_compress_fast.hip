@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     J = mj ? lane + (uint32_t)__builtin_ctzll(mj) : 64u;
                     S = ms ? lane + (uint32_t)__builtin_ctzll(ms) : 64u;
                 }
-                const uint32_t v_end = lane + kMinMatch + mlo;                    // anchor lane after a match at this lane
+                uint32_t v_end = lane + kMinMatch + mlo;                          // anchor lane after a match at this lane
+                uint32_t mlo_e = mlo, off_e = pos - old;                          // match length / offset the flush emits for a match lane
 
                 uint32_t f = 1;          // next lane to probe
                 uint32_t a = 0;          // lane of the current anchor
@@ -227,49 +228,50 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 bool continue_generic = false;
                 // with less than 512 bytes of room left every sequence takes the exact step, which checks the capacity
                 const bool tight = dst_len - op < 512u;
+                uint32_t a0 = a, op0 = op;   // anchor lane / output position at the start of the pending (unflushed) run
+                uint64_t mm_run = 0;         // match lanes of the pending run
+                // flush of the pending run: every offset from popcounts, three stores for all its sequences
+                auto flush_run = [&]() {
+                    const uint64_t mb = mm_run & lanes_below;
+                    const bool has_prev = mb != 0;
+                    const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;   // previous match lane
+                    const uint32_t pend_all = shfl(v_end, pj);          // (unconditional: see zlz4_device.hpp)
+                    const uint32_t pend = has_prev ? pend_all : a0;     // first lane of my literal run
+                    const bool cov = (covered & lane_bit) != 0;         // strictly inside a match
+                    const bool is_m = (mm_run & lane_bit) != 0;
+                    const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(mm_run);
+                    const bool is_lit = lane >= a0 && lane < jlast && !cov && !is_m;
+                    const uint64_t litmask = ballot(is_lit);
+                    const uint32_t k = (uint32_t)__popcll(mb);                          // sequences completed before me
+                    const uint32_t lb = (uint32_t)__popcll(litmask & lanes_below);      // literal bytes before me
+                    const uint32_t o1 = op0 + 3u * k + lb + 1u;
+                    if (is_lit) dst[o1] = (uint8_t)fwd.x;               // literals (:390)
+                    if (is_m) {
+                        const uint32_t lit_k = lane - pend;             // :360
+                        dst[o1 - 1u - lit_k] = (uint8_t)((lit_k << 4) | mlo_e);          // token
+                        const uint16_t off16 = (uint16_t)off_e;                          // :395
+                        __builtin_memcpy(dst + o1, &off16, 2);
+                    }
+                    const uint32_t nm = (uint32_t)__popcll(mm_run);
+                    op = op0 + 3u * nm + (uint32_t)__popcll(litmask);
+                    mm_run = 0;
+                };
                 for (;;) {
                     // ---- fast run: a minimal scalar loop that only collects the match lanes.  A search that
                     //      starts at f ends at J[f] when no slow lane comes first, the lane's hash is unique in the
                     //      window (its probe reads the pre-window value whatever was put before) and the literal
                     //      run fits the token nibble. ----
-                    const uint32_t a0 = a, op0 = op;
-                    uint64_t mm_run = 0;
+                    if (mm_run == 0) { a0 = a; op0 = op; }
                     // (the restart threshold 49 only applies once the window has produced a match: a window without
                     //  any match must scan all 64 lanes and hand the search over to the generic path)
-                    while (f < 64u && (f < 49u || (nseq == 0u && mm_run == 0))) {
+                    while (f < 64u && (f < 49u || nseq == 0u)) {
                         const uint32_t j = rdlane(J, f), sl = rdlane(S, f);
                         if (tight || sl <= j || j - a >= 15u || ((nsing >> j) & 1ull)) break;
                         mm_run |= 1ull << j;
+                        nseq++;
                         a = rdlane(v_end, j);                               // new anchor lane (:435)
+                        covered |= (a >= 64u ? ~0ull : (1ull << a) - 1ull) & ~((2ull << j) - 1ull);   // lanes j+1 .. a-1
                         f = a + 1u;                                         // put(anchor) happens via `ins` below
-                    }
-                    if (mm_run) {
-                        // ---- flush the run: every offset from popcounts, three stores for all its sequences ----
-                        const uint64_t mb = mm_run & lanes_below;
-                        const bool has_prev = mb != 0;
-                        const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;   // previous match lane
-                        const uint32_t pend_all = shfl(v_end, pj);          // (unconditional: see zlz4_device.hpp)
-                        const uint32_t pend = has_prev ? pend_all : a0;     // first lane of my literal run
-                        const bool cov = has_prev && lane < pend;           // strictly inside the previous match
-                        const bool is_m = (mm_run & lane_bit) != 0;
-                        const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(mm_run);
-                        const bool is_lit = lane >= a0 && lane < jlast && !cov && !is_m;
-                        const uint64_t litmask = ballot(is_lit);
-                        const uint32_t k = (uint32_t)__popcll(mb);                          // sequences completed before me
-                        const uint32_t lb = (uint32_t)__popcll(litmask & lanes_below);      // literal bytes before me
-                        const uint32_t o1 = op0 + 3u * k + lb + 1u;
-                        if (is_lit) dst[o1] = (uint8_t)fwd.x;               // literals (:390)
-                        if (is_m) {
-                            const uint32_t lit_k = lane - pend;             // :360
-                            dst[o1 - 1u - lit_k] = (uint8_t)((lit_k << 4) | mlo);            // token
-                            const uint16_t off16 = (uint16_t)(pos - old);                    // :395
-                            __builtin_memcpy(dst + o1, &off16, 2);
-                        }
-                        const uint32_t nm = (uint32_t)__popcll(mm_run);
-                        op = op0 + 3u * nm + (uint32_t)__popcll(litmask);
-                        covered |= ballot(cov);
-                        nseq += nm;
-                        STAMP_COUNT(9);
                     }
                     if (f >= 64u || (f >= 49u && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
                         if (nseq == 0u) continue_generic = true;    // every lane probed, no match
@@ -313,9 +315,24 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
                     else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
                     else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
-                    // immediate emission (:360-432), literals = low bytes of lanes a..j-1
                     const uint32_t lit = j - a;
                     const uint32_t offset = m_pos - m_cand;
+                    const uint32_t e = j + kMinMatch + mlen;                // lane of the new anchor (may be >= 64)
+                    if (!tight && lit < 15u && mlen < 15u) {
+                        // simple sequence: joins the pending run, emitted by the flush
+                        v_end = wrlane(e, j, v_end);
+                        mlo_e = wrlane(mlen, j, mlo_e);
+                        off_e = wrlane(offset, j, off_e);
+                        mm_run |= 1ull << j;
+                        nseq++;
+                        covered |= (e >= 64u ? ~0ull : (1ull << e) - 1ull) & ~((2ull << j) - 1ull);   // lanes j+1 .. e-1
+                        a = e;
+                        if (e >= 64u) break;                                // the next window inserts it as its lane 0
+                        f = e + 1u;
+                        continue;
+                    }
+                    if (mm_run) flush_run();
+                    // immediate emission (:360-432), literals = low bytes of lanes a..j-1
                     const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
                     const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
                     if (seq_end > dst_len) { failed = true; break; }
@@ -328,7 +345,6 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));
                     if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
                     op = (uint32_t)seq_end;
-                    const uint32_t e = j + kMinMatch + mlen;                // lane of the new anchor (may be >= 64)
                     {
                         const uint64_t upto_e = e >= 64u ? ~0ull : (1ull << e) - 1ull;
                         covered |= upto_e & ~((2ull << j) - 1ull);          // lanes j+1 .. e-1
@@ -338,6 +354,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     if (e >= 64u) break;                                    // the next window inserts it as its lane 0
                     f = e + 1u;
                 }
+                if (mm_run && !failed) flush_run();
                 anchor = A + a;
                 STAMP(4);
                 // lanes the serial loop put(): below the frontier and not strictly inside a match
