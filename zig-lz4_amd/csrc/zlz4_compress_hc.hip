@@ -172,21 +172,35 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
     uint32_t m = Links<T>::first(p, link[p]);                    // :563  hashTable[hashPtr(ip)]
     if (m != 0) {                                                // :566-568
         int32_t nb = max_attempts;
+        // the 16 bytes at p stay in registers: one 16-byte gather per candidate gives the 4-byte test (:586) and the
+        // first 12 bytes of lz4Count (:588) together
+        const bool wide = p + 16u <= n;
+        u32x4 p16 = {pattern, 0, 0, 0};
+        if (wide) p16 = ld128(src + p);
+        const uint32_t avail = limit - p;                        // lz4Count stops at iHighLimit
         while (m > 0 && nb > 0) {                                // :571
             if (m > p || (p - m) > kMaxDist) break;              // :573
             nb -= 1;                                             // :577
+            const T lk = link[m];                                // chain link, fetched together with the candidate bytes
             if (m >= lowest) {                                   // :579
-                if (ld32(src + m) == pattern) {                  // :586
-                    const int32_t mlt = (int32_t)(kMinMatch + lz4_count(src, p + kMinMatch, m + kMinMatch, limit));
-                    // back == 0: `ip > iLowLimit` is false (:596)
-                    if (mlt > best_len) {                        // :607
-                        best_len = mlt;
-                        best_off = p - m;
-                        if (mlt > max_attempts) break;           // :613
+                int32_t mlt = 0;
+                if (wide) {
+                    const uint32_t d = first_diff16(p16, ld128(src + m));    // m < p, so m + 16 <= n too
+                    if (d >= kMinMatch) {                        // :586
+                        if (d == 16u && avail > 16u) mlt = (int32_t)(16u + lz4_count(src, p + 16u, m + 16u, limit));
+                        else mlt = (int32_t)(d < avail ? d : avail);
                     }
+                } else if (ld32(src + m) == pattern) {           // :586 (the last <= 4 positions of a block)
+                    mlt = (int32_t)(kMinMatch + lz4_count(src, p + kMinMatch, m + kMinMatch, limit));
+                }
+                // back == 0: `ip > iLowLimit` is false (:596)
+                if (mlt > best_len) {                            // :607 (mlt == 0 when the 4 bytes differ)
+                    best_len = mlt;
+                    best_off = p - m;
+                    if (mlt > max_attempts) break;               // :613
                 }
             }
-            const uint32_t delta = Links<T>::delta(m, link[m]);  // :619
+            const uint32_t delta = Links<T>::delta(m, lk);       // :619
             if (delta == 0 || delta > m) break;                  // :620
             m -= delta;                                          // :621
         }
