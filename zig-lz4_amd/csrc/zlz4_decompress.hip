@@ -16,7 +16,34 @@
 
 #include "zlz4_device.hpp"
 
+// Diagnostic build only (-DZLZ4_STAMPS): per-phase shader-cycle sums of the wave decoder (tools/stamp_decode.py)
+#ifdef ZLZ4_STAMPS
+__device__ unsigned long long g_zlz4_dstamps[16];
+#define DSTAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define DSTAMP(i) do { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); \
+                      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define DSTAMP_ADD(i, n) do { st_acc[i] += (n); } while (0)
+#define DSTAMP_FLUSH do { if (lane == 0) for (int st_k = 0; st_k < 16; st_k++) atomicAdd(&g_zlz4_dstamps[st_k], st_acc[st_k]); } while (0)
+#else
+#define DSTAMP_DECL
+#define DSTAMP(i)
+#define DSTAMP_ADD(i, n)
+#define DSTAMP_FLUSH
+#endif
+
 namespace zlz4 {
+
+// inclusive prefix sum over the 64 lanes (DPP: Hillis-Steele inside each row of 16, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
 
 // kWrite == false: size pass (no stores) -- used by the frame decoder to learn every block's
 // decompressed size before placing the blocks (lz4f.decompressFrame accumulates dstPos serially).
@@ -41,6 +68,9 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
         // 64-byte register window over the compressed stream
         uint32_t wbase = 0;
         uint32_t w = (lane < iend) ? src[lane] : 0u;
+        uint32_t w4 = 0;                        // batch path: lane i holds src[ip + i .. ip + i + 3]
+        bool have4 = false;
+        DSTAMP_DECL
         auto reload = [&](uint32_t pos) {
             wbase = pos;
             w = (pos + lane < iend) ? src[pos + lane] : 0u;
@@ -52,6 +82,111 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
 
         for (;;) {
             if (ip >= iend) break;                                  // :113
+            // ---- batch path: every lane parses the 64-byte window as if a token started at its byte; a scalar walk
+            //      over next(i) picks the real token starts, and all sequences that lie entirely inside the window
+            //      (typically 6-9 on text) are copied together: one store writes every literal of the batch straight
+            //      from the window, then each sequence's lane moves its own match (<= 31 bytes, exact-size stores).
+            //      A sequence is only taken when it passes every check of :136-:186 trivially and its match source
+            //      ends before the first match of the batch; anything else (255-extension chains, long runs,
+            //      overlapping or very recent matches, the tail of the stream, malformed input) ends the batch in
+            //      front of it and goes through the single-sequence paths below, which hold the reference's
+            //      error order. ----
+            DSTAMP(6);
+            if ((uint64_t)ip + 68u <= iend) {
+                if (!have4) w4 = ld32(src + ip + lane);
+                have4 = false;
+                const uint32_t b0 = w4 & 0xFFu, b1 = (w4 >> 8) & 0xFFu;
+                uint32_t lit = b0 >> 4, hl = 1u;                    // :120
+                bool cx = false;
+                if (lit == 15u) { cx = (b1 == 255u); lit += b1; hl = 2u; }      // :123-131, one extension byte
+                const uint32_t mpos = lane + hl + lit;              // window index of the offset
+                const uint32_t mw = shfl(w4, mpos & 63u);           // offset (2 bytes) + first match-length extension byte
+                const uint32_t off = mw & 0xFFFFu;                  // :150
+                uint32_t mlc = b0 & 15u, slen = hl + lit + 2u;      // :157
+                if (mlc == 15u) { const uint32_t e2 = (mw >> 16) & 0xFFu; cx = cx || (e2 == 255u); mlc += e2; slen += 1u; }   // :160-168
+                const uint32_t ml = mlc + kMinMatch;                // :171, 4..273 here
+                const uint32_t nxt = lane + slen;
+                const bool ok = !cx && mpos <= 63u && nxt <= 64u && off != 0u;  // (:154 offset == 0 -> single path)
+                wbase = ip; w = b0;                                 // the single-sequence paths share this window
+                const uint32_t ol = lit + ml;                       // output bytes of the sequence (<= 335)
+                const uint32_t pkv = ok ? (nxt | (ol << 7)) : 0xFFFFFFFFu;      // sentinel: stops the walk
+                DSTAMP(0);
+                // :137, :174 -- and 32 bytes of slack for the 16-byte match loads
+                const uint32_t orem = oend - op;
+                const uint32_t room0 = kWrite ? (orem >= 32u ? orem - 32u : 0u) : orem;
+                const uint32_t room = room0 < 4095u ? room0 : 4095u;             // (relv must fit 16 bits of the literal lookup word)
+                uint32_t pos = 0, T = 0;
+                uint64_t R = 0;
+                do {
+                    const uint32_t pk = rdlane(pkv, pos);
+                    const uint32_t T2 = T + (pk >> 7);
+                    if (T2 > room) break;
+                    R |= 1ull << pos;
+                    T = T2;
+                    pos = pk & 127u;
+                } while (pos < 64u);
+                DSTAMP(1);
+                uint32_t relv = 0;
+                if (R != 0) {
+                    const bool real0 = (R >> lane) & 1ull;
+                    const uint32_t x = real0 ? ol : 0u;
+                    relv = wave_incl_scan(x) - x;                   // output offset of the sequence inside the batch
+                    // :181-186 / :231 offset > op, and (copy pass) a match source that reaches into this batch's
+                    // matches: end the batch in front of the first such sequence
+                    const uint32_t lit0 = rdlane(lit, 0);
+                    bool viol = off > op + relv + lit;
+                    if (kWrite) viol = viol || (off + lit0 < relv + ol);
+                    const uint64_t vm = ballot(real0 && viol);
+                    if (vm != 0) {
+                        const uint32_t fb = first_lane(vm);
+                        R &= (1ull << fb) - 1ull;
+                        T = rdlane(relv, fb);
+                        pos = fb;
+                    }
+                }
+                DSTAMP(2);
+                if (R != 0) {
+                    DSTAMP_ADD(8, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
+                    const uint32_t nip = ip + pos;
+                    uint32_t w4n = 0;
+                    const bool have_n = (uint64_t)nip + 68u <= iend;
+                    if (have_n) w4n = ld32(src + nip + lane);       // next window: in flight during the copies
+                    if (kWrite) {
+                        const bool real = (R >> lane) & 1ull;
+                        // literals (:140): window byte x belongs to the last token at or before x
+                        const uint64_t below = R & (~0ull >> (63u - lane));
+                        const uint32_t kl = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+                        const uint32_t q = shfl(relv | (lit << 16), kl);
+                        const uint32_t qlit = q >> 16;
+                        const uint32_t d = lane - kl - (qlit >= 15u ? 2u : 1u);
+                        if (d < qlit) dst[op + (q & 0xFFFFu) + d] = (uint8_t)b0;
+                        DSTAMP(3);
+                        // matches (:244): source entirely older than this batch's first match, no overlap
+                        if (real) {
+                            uint8_t *o = dst + op + relv + lit;
+                            const uint8_t *m = o - off;
+                            u32x4 v = ld128(m);
+                            uint32_t k = 0;
+                            if (ml >= 16u) {
+                                u32x4 v1 = ld128(m + 16u);
+                                st128(o, v); v = v1; k = 16u;
+                                while (ml - k >= 16u) { v1 = ld128(m + k + 16u); st128(o + k, v); v = v1; k += 16u; }
+                            }
+                            if (ml & 8u) { u32x2 h = {v.x, v.y}; __builtin_memcpy(o + k, &h, 8); v.x = v.z; v.y = v.w; k += 8u; }
+                            if (ml & 4u) { const uint32_t h = v.x; __builtin_memcpy(o + k, &h, 4); v.x = v.y; k += 4u; }
+                            if (ml & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(o + k, &h, 2); v.x >>= 16; k += 2u; }
+                            if (ml & 1u) o[k] = (uint8_t)v.x;
+                        }
+                        DSTAMP(4);
+                    }
+                    op += T;
+                    ip = nip;
+                    w4 = w4n;
+                    have4 = have_n;
+                    continue;
+                }
+            }
+            DSTAMP_ADD(11, 1);
             // ---- fast path: the whole sequence header (token, <= 14 literals, offset) sits inside the window,
             //      no length extension bytes.  Same checks in the same order as the general path below,
             //      written with 32-bit "remaining" arithmetic (ip <= iend and op <= oend always hold). ----
@@ -158,6 +293,8 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
             op += ml;
         }
         if (res == 0) res = (int64_t)op;                            // :250
+        DSTAMP(5);
+        DSTAMP_FLUSH;
     }
     if (lane == 0) d_result[blk] = res;
 }
@@ -307,8 +444,9 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
                                            const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                                            const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks) {
     if (nblocks == 0) return 0;
-    // large batches: one lane per block (64 blocks per wavefront); small batches: one wavefront per block
-    static const uint32_t lane_min = [] { const char *e = getenv("ZLZ4_DECOMP_LANE_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
+    // one wavefront per block (batch path) is the faster decoder at every batch size measured on MI355X; the
+    // one-lane-per-block kernel stays available behind ZLZ4_DECOMP_LANE_MIN (tests/test_gpu_lane_decoder.py)
+    static const uint32_t lane_min = [] { const char *e = getenv("ZLZ4_DECOMP_LANE_MIN"); return e ? (uint32_t)atoll(e) : 0xFFFFFFFFu; }();
     if (nblocks >= lane_min) {
         // the kernel is latency-bound: with few blocks use fewer lanes per wavefront so that ~8192 wavefronts exist
         static const uint32_t lanes_env = [] { const char *e = getenv("ZLZ4_DECOMP_LANES"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -340,3 +478,14 @@ extern "C" int zlz4_launch_decompress_sizes(hipStream_t stream, const uint8_t *d
                        d_in_len, (uint8_t *)nullptr, d_out_off, d_out_cap, d_result, nblocks);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
+
+#ifdef ZLZ4_STAMPS
+extern "C" int zlz4_debug_read_dstamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_zlz4_dstamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -7;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_zlz4_dstamps), z, sizeof z) != hipSuccess) return -7;
+    }
+    return 0;
+}
+#endif
