@@ -34,6 +34,9 @@ __device__ unsigned long long g_zlz4_dstamps[16];
 
 namespace zlz4 {
 
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
 // inclusive prefix sum over the 64 lanes (DPP: Hillis-Steele inside each row of 16, then row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
@@ -114,17 +117,45 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 // :137, :174 -- and 32 bytes of slack for the 16-byte match loads
                 const uint32_t orem = oend - op;
                 const uint32_t room0 = kWrite ? (orem >= 32u ? orem - 32u : 0u) : orem;
-                const uint32_t room = room0 < 4095u ? room0 : 4095u;             // (relv must fit 16 bits of the literal lookup word)
-                uint32_t pos = 0, T = 0;
-                uint64_t R = 0;
-                do {
-                    const uint32_t pk = rdlane(pkv, pos);
-                    const uint32_t T2 = T + (pk >> 7);
-                    if (T2 > room) break;
-                    R |= 1ull << pos;
-                    T = T2;
-                    pos = pk & 127u;
-                } while (pos < 64u);
+                const uint32_t room = rfl(room0 < 4095u ? room0 : 4095u);             // (relv must fit 16 bits of the literal lookup word)
+                // Scalar walk over the token chain: R = mask of real token starts, T = output bytes, pos = window index
+                // of the first token not taken.  Hand-scheduled (two hops per trip, the lane select of each
+                // v_readlane is written >= 8 instructions before it is used), 10 scalar instructions per hop:
+                //   do { pk = pkv[pos]; if (T + (pk >> 7) > room) break; R |= 1 << pos; T += pk >> 7; pos = pk & 127; } while (pos < 64);
+                uint32_t pos, T, wa, wpk, wt;
+                uint64_t R;
+                asm volatile(
+                    "s_mov_b64 %[R], 0\n\t"
+                    "s_mov_b32 %[T], 0\n\t"
+                    "s_mov_b32 %[A], 0\n\t"
+                    "s_nop 3\n"
+                    "1:\n\t"
+                    "v_readlane_b32 %[pk], %[pkv], %[A]\n\t"
+                    "s_and_b32 %[B], %[pk], 0x7f\n\t"
+                    "s_lshr_b32 %[t], %[pk], 7\n\t"
+                    "s_add_u32 %[t], %[t], %[T]\n\t"
+                    "s_cmp_gt_u32 %[t], %[room]\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_bitset1_b64 %[R], %[A]\n\t"
+                    "s_mov_b32 %[T], %[t]\n\t"
+                    "s_cmp_gt_u32 %[B], 63\n\t"
+                    "s_cbranch_scc1 4f\n\t"
+                    "v_readlane_b32 %[pk], %[pkv], %[B]\n\t"
+                    "s_and_b32 %[A], %[pk], 0x7f\n\t"
+                    "s_lshr_b32 %[t], %[pk], 7\n\t"
+                    "s_add_u32 %[t], %[t], %[T]\n\t"
+                    "s_cmp_gt_u32 %[t], %[room]\n\t"
+                    "s_cbranch_scc1 4f\n\t"
+                    "s_bitset1_b64 %[R], %[B]\n\t"
+                    "s_mov_b32 %[T], %[t]\n\t"
+                    "s_cmp_lt_u32 %[A], 64\n\t"
+                    "s_cbranch_scc1 1b\n"
+                    "3:\n\t"
+                    "s_mov_b32 %[B], %[A]\n"
+                    "4:\n"
+                    : [R] "=&s"(R), [T] "=&s"(T), [A] "=&s"(wa), [B] "=&s"(pos), [pk] "=&s"(wpk), [t] "=&s"(wt)
+                    : [pkv] "v"(pkv), [room] "s"(room)
+                    : "scc");
                 DSTAMP(1);
                 uint32_t relv = 0;
                 if (R != 0) {
@@ -165,17 +196,20 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                         if (real) {
                             uint8_t *o = dst + op + relv + lit;
                             const uint8_t *m = o - off;
-                            u32x4 v = ld128(m);
-                            uint32_t k = 0;
+                            // exact-size copies without partial-word stores: the last piece overlaps the one before it
                             if (ml >= 16u) {
-                                u32x4 v1 = ld128(m + 16u);
-                                st128(o, v); v = v1; k = 16u;
-                                while (ml - k >= 16u) { v1 = ld128(m + k + 16u); st128(o + k, v); v = v1; k += 16u; }
+                                u32x4 v = ld128(m);
+                                const u32x4 vt = ld128(m + ml - 16u);
+                                for (uint32_t k = 16u; k + 16u <= ml; k += 16u) { const u32x4 vn = ld128(m + k); st128(o + k - 16u, v); v = vn; }
+                                st128(o + ((ml - 16u) & ~15u), v);
+                                st128(o + ml - 16u, vt);
+                            } else if (ml >= 8u) {
+                                const uint64_t a = ld64u(m), b = ld64u(m + ml - 8u);
+                                __builtin_memcpy(o, &a, 8); __builtin_memcpy(o + ml - 8u, &b, 8);
+                            } else {
+                                const uint32_t a = ld32(m), b = ld32(m + ml - 4u);
+                                __builtin_memcpy(o, &a, 4); __builtin_memcpy(o + ml - 4u, &b, 4);
                             }
-                            if (ml & 8u) { u32x2 h = {v.x, v.y}; __builtin_memcpy(o + k, &h, 8); v.x = v.z; v.y = v.w; k += 8u; }
-                            if (ml & 4u) { const uint32_t h = v.x; __builtin_memcpy(o + k, &h, 4); v.x = v.y; k += 4u; }
-                            if (ml & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(o + k, &h, 2); v.x >>= 16; k += 2u; }
-                            if (ml & 1u) o[k] = (uint8_t)v.x;
                         }
                         DSTAMP(4);
                     }
@@ -307,8 +341,6 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
 // only ahead of the write position, where later output overwrites them (bytes between the returned size and
 // the capacity are unspecified, as in every wild-copy LZ4 decoder).  Output regions of different blocks must
 // therefore not overlap (the frame decoder passes the exact block size as capacity).
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
-__device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 __global__ __launch_bounds__(64) void k_decompress_lane(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
