@@ -40,8 +40,8 @@ for it in range(2):
     e1.record()
     torch.cuda.synchronize()
     L.zlz4_debug_read_dstamps(buf, 0)
-names = ["window wait + parse", "token walk", "scan + checks", "literal store", "match loads + stores",
-         "after last batch", "single-sequence paths / loop"]
+names = ["window wait + parse", "token walk", "scan + checks", "literal store", "match loads issue",
+         "after last batch", "single-sequence paths / loop", "deferred match stores (load wait)"]
 tot = sum(buf[i] for i in range(8))
 nb = max(1, buf[8])
 print("dist %s  blocks %d  kernel %.2f ms  round trip ok %s" % (dist, nblocks, e0.elapsed_time(e1), bool(torch.equal(out, inp))))

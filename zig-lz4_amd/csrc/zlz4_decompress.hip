@@ -71,9 +71,37 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
         // 64-byte register window over the compressed stream
         uint32_t wbase = 0;
         uint32_t w = (lane < iend) ? src[lane] : 0u;
-        uint32_t w4 = 0;                        // batch path: lane i holds src[ip + i .. ip + i + 3]
-        bool have4 = false;
         DSTAMP_DECL
+        // Match copies of a batch are split: the loads are issued with the batch, the stores are deferred until the
+        // next batch has been parsed (or until any other code touches dst), so the load round trip overlaps the
+        // parse and the token walk.  Per lane: pml = match length (0 = nothing pending), po = output offset,
+        // pof = match offset, pa / pb = first and last piece (16, 8 or 4 bytes each).
+        uint32_t pml = 0, po = 0, pof = 0;
+        u32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+        auto flush_pending = [&]() {
+            if (!kWrite) return;
+            if (pml != 0) {
+                uint8_t *o = dst + po;
+                if (pml >= 16u) {
+                    st128(o, pa);
+                    for (uint32_t k = 16u; k + 16u <= pml; k += 16u) st128(o + k, ld128(o - pof + k));
+                    st128(o + pml - 16u, pb);
+                } else if (pml >= 8u) {
+                    // exact-size copies without partial-word stores: the last piece overlaps the first
+                    const uint32_t sh = pml - 8u;                   // 0..7: bytes [sh, sh + 8) of pa
+                    const bool hi4 = sh >= 4u;
+                    const uint32_t x = hi4 ? pa.y : pa.x, y = hi4 ? pa.z : pa.y, z = hi4 ? pa.w : pa.z;
+                    const u32x2 a = {pa.x, pa.y};
+                    const u32x2 b = {__builtin_amdgcn_alignbyte(y, x, sh & 3u), __builtin_amdgcn_alignbyte(z, y, sh & 3u)};
+                    __builtin_memcpy(o, &a, 8); __builtin_memcpy(o + sh, &b, 8);
+                } else {
+                    const uint32_t sh = pml - 4u;                   // 0..3
+                    const uint32_t a = pa.x, b = __builtin_amdgcn_alignbyte(pa.y, pa.x, sh);
+                    __builtin_memcpy(o, &a, 4); __builtin_memcpy(o + sh, &b, 4);
+                }
+            }
+            pml = 0;
+        };
         auto reload = [&](uint32_t pos) {
             wbase = pos;
             w = (pos + lane < iend) ? src[pos + lane] : 0u;
@@ -96,8 +124,31 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
             //      error order. ----
             DSTAMP(6);
             if ((uint64_t)ip + 68u <= iend) {
-                if (!have4) w4 = ld32(src + ip + lane);
-                have4 = false;
+              // The window streams through three registers: X0 / X1 hold the dwords at xbase + lane and
+              // xbase + 64 + lane, X2 (xbase + 128 + lane) is a load in flight.  A batch consumes <= 64 bytes, so one
+              // shift per batch keeps ip inside [xbase, xbase + 64) and X2 is awaited a whole batch after its issue.
+              // X2 is loaded and awaited by hand (one `s_waitcnt vmcnt(0)` per batch, placed after the parse, where the
+              // previous batch's match data is needed anyway); the compiler, tracking it, would drain the queue at
+              // the top of every iteration.  X2 must not be touched between wload_async() and that wait.
+              auto woff = [&](uint32_t p) { const uint32_t a = p + lane; return a + 4u <= iend ? a : iend - 4u; };
+              auto wload_async = [&](uint32_t p) {
+                  uint32_t r;
+                  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(woff(p)), "s"(src) : "memory");
+                  return r;
+              };
+              uint32_t xbase = ip;
+              uint32_t X0 = ld32(src + woff(xbase)), X1 = ld32(src + woff(xbase + 64u));
+              uint32_t X2 = wload_async(xbase + 128u);
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(X0), "+v"(X1));
+              for (;;) {
+                {   // branch-free shift, one window load per batch
+                    const bool adv = ip - xbase >= 64u;
+                    X0 = adv ? X1 : X0; X1 = adv ? X2 : X1; xbase += adv ? 64u : 0u;
+                    X2 = wload_async(xbase + 128u);
+                }
+                const uint32_t xi = ip - xbase + lane;
+                const uint32_t xa = shfl(X0, xi & 63u), xb = shfl(X1, xi & 63u);
+                const uint32_t w4 = xi < 64u ? xa : xb;             // lane i: src[ip + i .. ip + i + 3]
                 const uint32_t b0 = w4 & 0xFFu, b1 = (w4 >> 8) & 0xFFu;
                 uint32_t lit = b0 >> 4, hl = 1u;                    // :120
                 bool cx = false;
@@ -110,7 +161,6 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 const uint32_t ml = mlc + kMinMatch;                // :171, 4..273 here
                 const uint32_t nxt = lane + slen;
                 const bool ok = !cx && mpos <= 63u && nxt <= 64u && off != 0u;  // (:154 offset == 0 -> single path)
-                wbase = ip; w = b0;                                 // the single-sequence paths share this window
                 const uint32_t ol = lit + ml;                       // output bytes of the sequence (<= 335)
                 const uint32_t pkv = ok ? (nxt | (ol << 7)) : 0xFFFFFFFFu;      // sentinel: stops the walk
                 DSTAMP(0);
@@ -176,50 +226,41 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     }
                 }
                 DSTAMP(2);
-                if (R != 0) {
-                    DSTAMP_ADD(8, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
-                    const uint32_t nip = ip + pos;
-                    uint32_t w4n = 0;
-                    const bool have_n = (uint64_t)nip + 68u <= iend;
-                    if (have_n) w4n = ld32(src + nip + lane);       // next window: in flight during the copies
-                    if (kWrite) {
-                        const bool real = (R >> lane) & 1ull;
-                        // literals (:140): window byte x belongs to the last token at or before x
-                        const uint64_t below = R & (~0ull >> (63u - lane));
-                        const uint32_t kl = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-                        const uint32_t q = shfl(relv | (lit << 16), kl);
-                        const uint32_t qlit = q >> 16;
-                        const uint32_t d = lane - kl - (qlit >= 15u ? 2u : 1u);
-                        if (d < qlit) dst[op + (q & 0xFFFFu) + d] = (uint8_t)b0;
-                        DSTAMP(3);
-                        // matches (:244): source entirely older than this batch's first match, no overlap
-                        if (real) {
-                            uint8_t *o = dst + op + relv + lit;
-                            const uint8_t *m = o - off;
-                            // exact-size copies without partial-word stores: the last piece overlaps the one before it
-                            if (ml >= 16u) {
-                                u32x4 v = ld128(m);
-                                const u32x4 vt = ld128(m + ml - 16u);
-                                for (uint32_t k = 16u; k + 16u <= ml; k += 16u) { const u32x4 vn = ld128(m + k); st128(o + k - 16u, v); v = vn; }
-                                st128(o + ((ml - 16u) & ~15u), v);
-                                st128(o + ml - 16u, vt);
-                            } else if (ml >= 8u) {
-                                const uint64_t a = ld64u(m), b = ld64u(m + ml - 8u);
-                                __builtin_memcpy(o, &a, 8); __builtin_memcpy(o + ml - 8u, &b, 8);
-                            } else {
-                                const uint32_t a = ld32(m), b = ld32(m + ml - 4u);
-                                __builtin_memcpy(o, &a, 4); __builtin_memcpy(o + ml - 4u, &b, 4);
-                            }
-                        }
-                        DSTAMP(4);
+                // The one wait of a batch: the window load issued at the top of this iteration and the match loads of
+                // the previous batch have had the whole parse / walk / scan to arrive.
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2));
+                if (R == 0) break;                                  // the single-sequence paths take this one
+                DSTAMP_ADD(8, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
+                if (kWrite) {
+                    flush_pending();                                // the previous batch's match stores
+                    DSTAMP(7);
+                    // literals (:140): window byte x belongs to the last token at or before x
+                    const uint64_t below = R & (~0ull >> (63u - lane));
+                    const uint32_t kl = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+                    const uint32_t q = shfl(relv | (lit << 16), kl);
+                    const uint32_t qlit = q >> 16;
+                    const uint32_t d = lane - kl - (qlit >= 15u ? 2u : 1u);
+                    if (d < qlit) dst[op + (q & 0xFFFFu) + d] = (uint8_t)b0;
+                    DSTAMP(3);
+                    // matches (:244): source entirely older than this batch's first match, no overlap.  One or two
+                    // 16-byte loads per sequence lane; the data is stored by flush_pending() after the next batch
+                    // has been parsed.
+                    const bool real = (R >> lane) & 1ull;
+                    if (real) {
+                        const uint8_t *m = dst + (op + relv + lit - off);
+                        pa = ld128(m);
+                        if (ml >= 16u) pb = ld128(m + ml - 16u);
+                        pml = ml; po = op + relv + lit; pof = off;
                     }
-                    op += T;
-                    ip = nip;
-                    w4 = w4n;
-                    have4 = have_n;
-                    continue;
+                    DSTAMP(4);
                 }
+                op += T;
+                ip += pos;
+                if ((uint64_t)ip + 68u > iend) break;
+              }
+              if (ip >= iend) { flush_pending(); break; }
             }
+            flush_pending();
             DSTAMP_ADD(11, 1);
             // ---- fast path: the whole sequence header (token, <= 14 literals, offset) sits inside the window,
             //      no length extension bytes.  Same checks in the same order as the general path below,
@@ -326,6 +367,7 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
             }
             op += ml;
         }
+        flush_pending();
         if (res == 0) res = (int64_t)op;                            // :250
         DSTAMP(5);
         DSTAMP_FLUSH;
@@ -494,7 +536,9 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
     }
     const uint32_t waves_per_wg = 4;
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
-    hipLaunchKernelGGL(zlz4::k_decompress_safe<true>, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
+    // experiment knob: dynamic LDS per workgroup only to limit the number of resident wavefronts per CU
+    static const uint32_t dyn_lds = [] { const char *e = getenv("ZLZ4_DECOMP_LDS"); return e ? (uint32_t)atoll(e) : 0u; }();
+    hipLaunchKernelGGL(zlz4::k_decompress_safe<true>, dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in, d_in_off,
                        d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
