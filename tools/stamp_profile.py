@@ -25,7 +25,7 @@ comp = torch.empty(nblocks * slot, dtype=torch.uint8, device=dev)
 res = torch.empty(nblocks, dtype=torch.int64, device=dev)
 L = zl.lib()
 L.zlz4_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 24)()
 for it in range(2):
     L.zlz4_debug_read_stamps(buf, 1)
     torch.cuda.synchronize()
@@ -35,12 +35,14 @@ for it in range(2):
     e1.record()
     torch.cuda.synchronize()
     L.zlz4_debug_read_stamps(buf, 0)
-names = ["table init", "forward load", "table rd/put/readback/groups", "candidate gather", "restore/commit/local ext",
-         "cooperative extension", "emission", "tail literals"]
-tot = sum(buf[i] for i in range(8))
-print("dist %s  blocks %d  kernel %.2f ms  batches %d  sequences %d  (%.1f seq/block, %.2f batches/seq)" % (
-    dist, nblocks, e0.elapsed_time(e1), buf[8], buf[9], buf[9] / nblocks, buf[8] / max(1, buf[9])))
-for i, n in enumerate(names):
-    print("  %-32s %6.2f %%   %8.0f cycles/sequence" % (n, 100.0 * buf[i] / tot, buf[i] / max(1, buf[9])))
-print("  total wave-cycles/sequence %.0f" % (tot / max(1, buf[9])))
-print("  window sequences %d  slow matches %d  slow failed probes %d  generic-path sequences %d" % (buf[9], buf[10], buf[11], buf[12]))
+names = {0: "table init", 1: "forward load + hash", 3: "table read + gather issue", 2: "put / read-back / groups",
+         6: "vector prep (vo, mlo, J/S)", 8: "fast-run scalar loop", 9: "exact steps / loop misc", 10: "flush (emission)",
+         4: "after loop", 5: "restore / commit", 7: "tail literals + generic path"}
+tot = sum(buf[i] for i in range(12))
+nw = max(1, buf[16])
+print("dist %s  blocks %d  kernel %.2f ms  windows %d (%.1f / block)" % (dist, nblocks, e0.elapsed_time(e1), buf[16], buf[16] / nblocks))
+print("per window: fast-run sequences %.2f  exact matches %.2f  exact failed probes %.2f  flushes %.2f ; generic-path sequences %d" % (
+    buf[17] / nw, buf[18] / nw, buf[19] / nw, buf[21] / nw, buf[20]))
+for i, n in names.items():
+    print("  %-32s %6.2f %%   %8.0f cycles/window" % (n, 100.0 * buf[i] / tot, buf[i] / nw))
+print("  total wave-cycles/window %.0f" % (tot / nw))

@@ -32,13 +32,13 @@
 
 // Diagnostic build only (-DZLZ4_STAMPS): per-phase shader-cycle sums, see profiles/ notes.
 #ifdef ZLZ4_STAMPS
-__device__ unsigned long long g_zlz4_stamps[16];
-#define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long g_zlz4_stamps[24];
+#define STAMP_DECL unsigned long long st_acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #define STAMP(i) do { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); \
                       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now) :: "memory"); \
                       __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
 #define STAMP_COUNT(i) do { st_acc[i] += 1; } while (0)
-#define STAMP_FLUSH do { if (lane == 0) for (int st_k = 0; st_k < 16; st_k++) atomicAdd(&g_zlz4_stamps[st_k], st_acc[st_k]); } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int st_k = 0; st_k < 24; st_k++) atomicAdd(&g_zlz4_stamps[st_k], st_acc[st_k]); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const u32x4 fwd = ld128(src + pos);
                 const uint32_t h = hash4(fwd.x);                        // :341
                 STAMP(1);
-                STAMP_COUNT(8);
+                STAMP_COUNT(16);
                 uint32_t old = 0, rb = 0;
                 if (wr) old = table[h];                                 // :342
                 // pre-window candidates: the old table value passes `match > 0`, `match < ip` (always) and
@@ -204,11 +204,14 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                              : (x2 ? 4u + ((uint32_t)__builtin_ctz(x2) >> 3)
                                    : (x3 ? 8u + ((uint32_t)__builtin_ctz(x3) >> 3) : 12u));
                 }
+                // second level: the few lanes whose 16 bytes all match compare 16 more (matches of 16..31 bytes are a
+                // fifth of all sequences on text; without this each of them costs an exact step and its own emission)
+                if (vo && mlo == 12u) mlo += first_diff16(ld128(src + pos + 16u), ld128(src + old + 16u));
                 const bool single = grp == lane_bit;
-                const bool oldfast = vo && mlo < 12u;         // result against the pre-window value is complete in registers
+                const bool oldfast = vo && mlo < 28u;         // result against the pre-window value is complete in registers
                 const uint64_t wrmask = ballot(wr);
                 const uint64_t cfast = ballot(oldfast);                                       // usable if no in-window put precedes
-                const uint64_t slow = ballot(wr && ((!single && !oldfast) || (vo && mlo >= 12u)));   // exact step if reached
+                const uint64_t slow = ballot(wr && ((!single && !oldfast) || (vo && mlo >= 28u)));   // exact step if reached
                 const uint64_t nsing = ballot(wr && !single);
                 // per lane i: J = first cfast lane >= i, S = first slow lane >= i (64 = none),
                 // E = lane of the new anchor if the search that starts at i ends with the match at J
@@ -220,41 +223,65 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 }
                 uint32_t v_end = lane + kMinMatch + mlo;                          // anchor lane after a match at this lane
                 uint32_t mlo_e = mlo, off_e = pos - old;                          // match length / offset the flush emits for a match lane
+                // fast-run step of a search that starts at lane f, precomputed for every f: PK = j | (v_end[j] << 6) when
+                // the search ends with the in-register match at j = J[f] (no slow lane first, j's hash unique in the
+                // window), else ~0.  (Exact steps only rewrite v_end of lanes the search has already passed.)
+                uint32_t PK;
+                {
+                    const uint32_t jc = J & 63u;
+                    const uint32_t ve_j = shfl(v_end, jc);
+                    const bool fastok = J < 64u && S > J && !((nsing >> jc) & 1ull);
+                    PK = fastok ? (J | (ve_j << 6)) : 0xFFFFFFFFu;
+                }
 
+                STAMP(6);
                 uint32_t f = 1;          // next lane to probe
                 uint32_t a = 0;          // lane of the current anchor
                 uint32_t nseq = 0;
-                uint64_t covered = 0;    // lanes strictly inside a match: never put() (Q6)
+                uint64_t covered_x = 0;  // lanes strictly inside a match that was emitted immediately (Q6: never put())
+                uint64_t mm_win = 0;     // match lanes of the runs already flushed
                 bool continue_generic = false;
                 // with less than 512 bytes of room left every sequence takes the exact step, which checks the capacity
                 const bool tight = dst_len - op < 512u;
                 uint32_t a0 = a, op0 = op;   // anchor lane / output position at the start of the pending (unflushed) run
                 uint64_t mm_run = 0;         // match lanes of the pending run
+                // lanes strictly inside a match so far (never put(), Q6): from the match lanes and their end lanes
+                auto covered_now = [&]() -> uint64_t {
+                    const uint64_t mb = (mm_win | mm_run) & lanes_below;
+                    const uint32_t pj = mb ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;
+                    const uint32_t pe = shfl(v_end, pj);                // (unconditional: see zlz4_device.hpp)
+                    return covered_x | ballot(mb != 0 && lane < pe);
+                };
                 // flush of the pending run: every offset from popcounts, three stores for all its sequences
                 auto flush_run = [&]() {
+                    STAMP(9); STAMP_COUNT(21);
                     const uint64_t mb = mm_run & lanes_below;
                     const bool has_prev = mb != 0;
                     const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;   // previous match lane
                     const uint32_t pend_all = shfl(v_end, pj);          // (unconditional: see zlz4_device.hpp)
                     const uint32_t pend = has_prev ? pend_all : a0;     // first lane of my literal run
-                    const bool cov = (covered & lane_bit) != 0;         // strictly inside a match
+                    const bool cov = has_prev && lane < pend_all;       // strictly inside a match of this run
                     const bool is_m = (mm_run & lane_bit) != 0;
                     const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(mm_run);
                     const bool is_lit = lane >= a0 && lane < jlast && !cov && !is_m;
                     const uint64_t litmask = ballot(is_lit);
+                    const uint64_t extm = ballot(is_m && mlo_e >= 15u);                 // matches with one length-extension byte (:416-429)
                     const uint32_t k = (uint32_t)__popcll(mb);                          // sequences completed before me
                     const uint32_t lb = (uint32_t)__popcll(litmask & lanes_below);      // literal bytes before me
-                    const uint32_t o1 = op0 + 3u * k + lb + 1u;
+                    const uint32_t o1 = op0 + 3u * k + lb + 1u + (uint32_t)__popcll(extm & lanes_below);
                     if (is_lit) dst[o1] = (uint8_t)fwd.x;               // literals (:390)
                     if (is_m) {
                         const uint32_t lit_k = lane - pend;             // :360
-                        dst[o1 - 1u - lit_k] = (uint8_t)((lit_k << 4) | mlo_e);          // token
+                        dst[o1 - 1u - lit_k] = (uint8_t)((lit_k << 4) | (mlo_e < 15u ? mlo_e : 15u));   // token
                         const uint16_t off16 = (uint16_t)off_e;                          // :395
                         __builtin_memcpy(dst + o1, &off16, 2);
+                        if (mlo_e >= 15u) dst[o1 + 2u] = (uint8_t)(mlo_e - 15u);         // < 255: the run ends here
                     }
                     const uint32_t nm = (uint32_t)__popcll(mm_run);
-                    op = op0 + 3u * nm + (uint32_t)__popcll(litmask);
+                    op = op0 + 3u * nm + (uint32_t)__popcll(litmask) + (uint32_t)__popcll(extm);
+                    mm_win |= mm_run;
                     mm_run = 0;
+                    STAMP(10);
                 };
                 for (;;) {
                     // ---- fast run: a minimal scalar loop that only collects the match lanes.  A search that
@@ -265,14 +292,16 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     // (the restart threshold 49 only applies once the window has produced a match: a window without
                     //  any match must scan all 64 lanes and hand the search over to the generic path)
                     while (f < 64u && (f < 49u || nseq == 0u)) {
-                        const uint32_t j = rdlane(J, f), sl = rdlane(S, f);
-                        if (tight || sl <= j || j - a >= 15u || ((nsing >> j) & 1ull)) break;
+                        const uint32_t pk = rdlane(PK, f);
+                        const uint32_t j = pk & 63u;
+                        if (tight || pk == 0xFFFFFFFFu || j - a >= 15u) break;
                         mm_run |= 1ull << j;
                         nseq++;
-                        a = rdlane(v_end, j);                               // new anchor lane (:435)
-                        covered |= (a >= 64u ? ~0ull : (1ull << a) - 1ull) & ~((2ull << j) - 1ull);   // lanes j+1 .. a-1
+                        STAMP_COUNT(17);
+                        a = pk >> 6;                                        // new anchor lane (:435)
                         f = a + 1u;                                         // put(anchor) happens via `ins` below
                     }
+                    STAMP(8);
                     if (f >= 64u || (f >= 49u && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
                         if (nseq == 0u) continue_generic = true;    // every lane probed, no match
                         break;
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     uint64_t pm = 0;
                     if ((nsing >> x) & 1ull) {
                         const uint64_t grp_x = (uint64_t)rdlane((uint32_t)grp, x) | ((uint64_t)rdlane((uint32_t)(grp >> 32), x) << 32);
-                        pm = grp_x & wrmask & ~covered & ((1ull << x) - 1ull);
+                        pm = grp_x & wrmask & ~covered_now() & ((1ull << x) - 1ull);
                     }
                     uint32_t m_cand, cy, cz, cw;
                     bool ok;
@@ -305,8 +334,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                         m_cand = rdlane(old, x);
                         cy = rdlane(cold.y, x); cz = rdlane(cold.z, x); cw = rdlane(cold.w, x);
                     }
-                    if (!ok) { STAMP_COUNT(11); f = x + 1u; continue; }      // probed, put, no match: next probe
-                    STAMP_COUNT(10);
+                    if (!ok) { STAMP_COUNT(19); STAMP(9); f = x + 1u; continue; }      // probed, put, no match: next probe
+                    STAMP_COUNT(18);
                     const uint32_t j = x;
                     const uint32_t m_pos = A + j;
                     const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ cz) << 32) | (rdlane(fwd.y, j) ^ cy);
@@ -325,8 +354,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                         off_e = wrlane(offset, j, off_e);
                         mm_run |= 1ull << j;
                         nseq++;
-                        covered |= (e >= 64u ? ~0ull : (1ull << e) - 1ull) & ~((2ull << j) - 1ull);   // lanes j+1 .. e-1
                         a = e;
+                        STAMP(9);
                         if (e >= 64u) break;                                // the next window inserts it as its lane 0
                         f = e + 1u;
                         continue;
@@ -347,7 +376,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     op = (uint32_t)seq_end;
                     {
                         const uint64_t upto_e = e >= 64u ? ~0ull : (1ull << e) - 1ull;
-                        covered |= upto_e & ~((2ull << j) - 1ull);          // lanes j+1 .. e-1
+                        covered_x |= upto_e & ~((2ull << j) - 1ull);        // lanes j+1 .. e-1
                     }
                     nseq++;
                     a = e;
@@ -359,7 +388,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 STAMP(4);
                 // lanes the serial loop put(): below the frontier and not strictly inside a match
                 const uint32_t f_end = continue_generic ? 64u : (a >= 64u ? 64u : a + 1u);
-                const uint64_t ins = wrmask & ~covered & (f_end >= 64u ? ~0ull : (1ull << f_end) - 1ull);
+                const uint64_t ins = wrmask & ~covered_now() & (f_end >= 64u ? ~0ull : (1ull << f_end) - 1ull);
                 if (failed) break;
                 // ---- leave the table as the serial loop would have ----
                 if (wr && !(ins & lane_bit)) table[h] = (T)old;
@@ -484,7 +513,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 ub += 64;
             }
             if (bailed || !found) break;
-            STAMP_COUNT(12);
+            STAMP_COUNT(20);
 
             // ---------------- forward extension (:401-413) ----------------
             const uint32_t mlen = m_local_done ? m_local
@@ -547,9 +576,9 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
 
 #ifdef ZLZ4_STAMPS
 extern "C" int zlz4_debug_read_stamps(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_zlz4_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -7;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_zlz4_stamps), 24 * sizeof(unsigned long long)) != hipSuccess) return -7;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[24] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_zlz4_stamps), z, sizeof z) != hipSuccess) return -7;
     }
     return 0;
