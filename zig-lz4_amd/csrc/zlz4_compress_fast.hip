@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void k_compress_fast(
     if (blk >= nblocks) return;
     // HashTable, src/lz4.zig:263-277.  volatile: lanes communicate through it (write / read-back race
     // detection), so the compiler must neither forward stores to loads nor drop the re-reads.
-    volatile T *table = reinterpret_cast<volatile T *>(lds_raw) + wave_in_wg * 4096u;
+    // (typed as address space 3: a generic `volatile T *` would compile to FLAT loads/stores with a full
+    //  `s_waitcnt vmcnt(0)` each, i.e. every table access would also wait for the global gathers in flight)
+    typedef __attribute__((address_space(3))) volatile T lds_entry;
+    lds_entry *table = (lds_entry *)lds_raw + wave_in_wg * 4096u;
 
     const uint8_t *src = d_in + d_in_off[blk];
     uint8_t *dst = d_out + d_out_off[blk];

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
     const uint32_t n = rfl(d_in_len[blk0 + b]);
     const uint32_t np = n_positions(n);
     T *link = d_link + (uint64_t)b * link_stride;
-    volatile T *table = reinterpret_cast<volatile T *>(lds_raw);
+    typedef __attribute__((address_space(3))) volatile T lds_entry;   // (AS3-typed: ds_read / ds_write, not FLAT)
+    lds_entry *table = (lds_entry *)lds_raw;
     {
         u32x4 z = {0, 0, 0, 0};
         u32x4 *t4 = reinterpret_cast<u32x4 *>(lds_raw);
