@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void k_compress_fast(
         STAMP(0);   // table init
 
         uint32_t guard = 0;      // every round of this loop consumes at least one input byte
+        // forward bytes of the next window, loaded as soon as its anchor is known (before the emission and the table
+        // fix-up of the current window, which hide the load)
+        u32x4 fwd_pf = {0, 0, 0, 0};
+        uint32_t pf_anchor = 0xFFFFFFFFu;
         while (F0 < L) {                                                // :320
             if (++guard > src_size) { failed = true; break; }           // unreachable; never spin on the GPU
             int32_t ub = -1;      // probe index of lane 0 of the next generic batch (-1 = pending insert pseudo-probe)
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const uint32_t A = anchor;
                 const uint32_t pos = A + lane;
                 const bool wr = has_ins || lane > 0;                    // position 0 is never inserted (Q1)
-                const u32x4 fwd = ld128(src + pos);
+                const u32x4 fwd = (pf_anchor == A) ? fwd_pf : ld128(src + pos);
                 const uint32_t h = hash4(fwd.x);                        // :341
                 STAMP(1);
                 STAMP_COUNT(16);
@@ -385,6 +389,10 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     a = e;
                     if (e >= 64u) break;                                    // the next window inserts it as its lane 0
                     f = e + 1u;
+                }
+                if (!continue_generic && !failed && a != 0u && (uint64_t)A + a + 192u < L) {
+                    pf_anchor = A + a;
+                    fwd_pf = ld128(src + pf_anchor + lane);
                 }
                 if (mm_run && !failed) flush_run();
                 anchor = A + a;
