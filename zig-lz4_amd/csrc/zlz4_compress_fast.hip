@@ -298,15 +298,38 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     if (mm_run == 0) { a0 = a; op0 = op; }
                     // (the restart threshold 49 only applies once the window has produced a match: a window without
                     //  any match must scan all 64 lanes and hand the search over to the generic path)
-                    while (f < 64u && (f < 49u || nseq == 0u)) {
-                        const uint32_t pk = rdlane(PK, f);
-                        const uint32_t j = pk & 63u;
-                        if (tight || pk == 0xFFFFFFFFu || j - a >= 15u) break;
-                        mm_run |= 1ull << j;
-                        nseq++;
-                        STAMP_COUNT(17);
-                        a = pk >> 6;                                        // new anchor lane (:435)
-                        f = a + 1u;                                         // put(anchor) happens via `ins` below
+                    if (!tight) {
+                        // hand-scheduled scalar loop (the compiler spends ~25 scalar instructions per trip on the
+                        // boolean plumbing; the scalar unit is what bounds this kernel):
+                        //   while (f < 64 && (f < 49 || nseq == 0)) { pk = PK[f]; j = pk & 63; if (pk == ~0 || j - a >= 15) break;
+                        //                                               mm_run |= 1 << j; nseq++; a = pk >> 6; f = a + 1; }
+                        uint32_t t_pk, t_j, t_d;
+                        asm volatile(
+                            "s_nop 3\n"
+                            "1:\n\t"
+                            "s_cmp_gt_u32 %[f], 63\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_cmp_lt_u32 %[f], 49\n\t"
+                            "s_cbranch_scc1 2f\n\t"
+                            "s_cmp_eq_u32 %[nseq], 0\n\t"
+                            "s_cbranch_scc0 3f\n"
+                            "2:\n\t"
+                            "v_readlane_b32 %[pk], %[PK], %[f]\n\t"
+                            "s_cmp_eq_u32 %[pk], -1\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_and_b32 %[j], %[pk], 63\n\t"
+                            "s_sub_u32 %[d], %[j], %[a]\n\t"
+                            "s_cmp_gt_u32 %[d], 14\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_bitset1_b64 %[mm], %[j]\n\t"
+                            "s_add_u32 %[nseq], %[nseq], 1\n\t"
+                            "s_lshr_b32 %[a], %[pk], 6\n\t"
+                            "s_add_u32 %[f], %[a], 1\n\t"
+                            "s_branch 1b\n"
+                            "3:\n"
+                            : [f] "+s"(f), [a] "+s"(a), [nseq] "+s"(nseq), [mm] "+s"(mm_run), [pk] "=&s"(t_pk), [j] "=&s"(t_j), [d] "=&s"(t_d)
+                            : [PK] "v"(PK)
+                            : "scc");
                     }
                     STAMP(8);
                     if (f >= 64u || (f >= 49u && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
