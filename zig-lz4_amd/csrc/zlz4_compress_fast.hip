@@ -214,11 +214,12 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 // second level: the few lanes whose 16 bytes all match compare 16 more (matches of 16..31 bytes are a
                 // fifth of all sequences on text; without this each of them costs an exact step and its own emission)
                 if (vo && mlo == 12u) mlo += first_diff16(ld128(src + pos + 16u), ld128(src + old + 16u));
+                if (vo && mlo == 28u) mlo += first_diff16(ld128(src + pos + 32u), ld128(src + old + 32u));
                 const bool single = grp == lane_bit;
-                const bool oldfast = vo && mlo < 28u;         // result against the pre-window value is complete in registers
+                const bool oldfast = vo && mlo < 44u;         // result against the pre-window value is complete in registers
                 const uint64_t wrmask = ballot(wr);
                 const uint64_t cfast = ballot(oldfast);                                       // usable if no in-window put precedes
-                const uint64_t slow = ballot(wr && ((!single && !oldfast) || (vo && mlo >= 28u)));   // exact step if reached
+                const uint64_t slow = ballot(wr && ((!single && !oldfast) || (vo && mlo >= 44u)));   // exact step if reached
                 const uint64_t nsing = ballot(wr && !single);
                 // per lane i: J = first cfast lane >= i, S = first slow lane >= i (64 = none),
                 // E = lane of the new anchor if the search that starts at i ends with the match at J
@@ -273,19 +274,28 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     const bool is_lit = lane >= a0 && lane < jlast && !cov && !is_m;
                     const uint64_t litmask = ballot(is_lit);
                     const uint64_t extm = ballot(is_m && mlo_e >= 15u);                 // matches with one length-extension byte (:416-429)
+                    // literal runs of 15..63 bytes carry one extension byte too (:368-382): a lane's sequence is the
+                    // first match lane at or above it, its literal count that lane minus the start of the run
+                    const uint64_t at_or_above = mm_run & ~lanes_below;
+                    const uint32_t my_m = at_or_above ? (uint32_t)__builtin_ctzll(at_or_above) : lane;
+                    const uint32_t own_l = (my_m - pend >= 15u) ? 1u : 0u;
+                    const uint64_t lextm = ballot(is_m && own_l != 0u);
                     const uint32_t k = (uint32_t)__popcll(mb);                          // sequences completed before me
                     const uint32_t lb = (uint32_t)__popcll(litmask & lanes_below);      // literal bytes before me
-                    const uint32_t o1 = op0 + 3u * k + lb + 1u + (uint32_t)__popcll(extm & lanes_below);
+                    const uint32_t o1 = op0 + 3u * k + lb + 1u + (uint32_t)__popcll(extm & lanes_below) +
+                                        (uint32_t)__popcll(lextm & lanes_below) + own_l;
                     if (is_lit) dst[o1] = (uint8_t)fwd.x;               // literals (:390)
                     if (is_m) {
                         const uint32_t lit_k = lane - pend;             // :360
-                        dst[o1 - 1u - lit_k] = (uint8_t)((lit_k << 4) | (mlo_e < 15u ? mlo_e : 15u));   // token
+                        uint8_t *tk = dst + (o1 - 1u - lit_k - own_l);
+                        tk[0] = (uint8_t)(((lit_k < 15u ? lit_k : 15u) << 4) | (mlo_e < 15u ? mlo_e : 15u));   // token
+                        if (own_l) tk[1] = (uint8_t)(lit_k - 15u);
                         const uint16_t off16 = (uint16_t)off_e;                          // :395
                         __builtin_memcpy(dst + o1, &off16, 2);
-                        if (mlo_e >= 15u) dst[o1 + 2u] = (uint8_t)(mlo_e - 15u);         // < 255: the run ends here
+                        if (mlo_e >= 15u) dst[o1 + 2u] = (uint8_t)(mlo_e - 15u);         // < 255 (mlen < 270 in a run)
                     }
                     const uint32_t nm = (uint32_t)__popcll(mm_run);
-                    op = op0 + 3u * nm + (uint32_t)__popcll(litmask) + (uint32_t)__popcll(extm);
+                    op = op0 + 3u * nm + (uint32_t)__popcll(litmask) + (uint32_t)__popcll(extm) + (uint32_t)__popcll(lextm);
                     mm_win |= mm_run;
                     mm_run = 0;
                     STAMP(10);
@@ -301,9 +311,9 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     if (!tight) {
                         // hand-scheduled scalar loop (the compiler spends ~25 scalar instructions per trip on the
                         // boolean plumbing; the scalar unit is what bounds this kernel):
-                        //   while (f < 64 && (f < 49 || nseq == 0)) { pk = PK[f]; j = pk & 63; if (pk == ~0 || j - a >= 15) break;
+                        //   while (f < 64 && (f < 49 || nseq == 0)) { pk = PK[f]; j = pk & 63; if (pk == ~0) break;
                         //                                               mm_run |= 1 << j; nseq++; a = pk >> 6; f = a + 1; }
-                        uint32_t t_pk, t_j, t_d;
+                        uint32_t t_pk, t_j;
                         asm volatile(
                             "s_nop 3\n"
                             "1:\n\t"
@@ -318,16 +328,13 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                             "s_cmp_eq_u32 %[pk], -1\n\t"
                             "s_cbranch_scc1 3f\n\t"
                             "s_and_b32 %[j], %[pk], 63\n\t"
-                            "s_sub_u32 %[d], %[j], %[a]\n\t"
-                            "s_cmp_gt_u32 %[d], 14\n\t"
-                            "s_cbranch_scc1 3f\n\t"
                             "s_bitset1_b64 %[mm], %[j]\n\t"
                             "s_add_u32 %[nseq], %[nseq], 1\n\t"
                             "s_lshr_b32 %[a], %[pk], 6\n\t"
                             "s_add_u32 %[f], %[a], 1\n\t"
                             "s_branch 1b\n"
                             "3:\n"
-                            : [f] "+s"(f), [a] "+s"(a), [nseq] "+s"(nseq), [mm] "+s"(mm_run), [pk] "=&s"(t_pk), [j] "=&s"(t_j), [d] "=&s"(t_d)
+                            : [f] "+s"(f), [a] "+s"(a), [nseq] "+s"(nseq), [mm] "+s"(mm_run), [pk] "=&s"(t_pk), [j] "=&s"(t_j)
                             : [PK] "v"(PK)
                             : "scc");
                     }
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     const uint32_t lit = j - a;
                     const uint32_t offset = m_pos - m_cand;
                     const uint32_t e = j + kMinMatch + mlen;                // lane of the new anchor (may be >= 64)
-                    if (!tight && lit < 15u && mlen < 15u) {
+                    if (!tight && mlen < 270u) {
                         // simple sequence: joins the pending run, emitted by the flush
                         v_end = wrlane(e, j, v_end);
                         mlo_e = wrlane(mlen, j, mlo_e);
