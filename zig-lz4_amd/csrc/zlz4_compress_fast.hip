@@ -213,8 +213,12 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 }
                 // second level: the few lanes whose 16 bytes all match compare 16 more (matches of 16..31 bytes are a
                 // fifth of all sequences on text; without this each of them costs an exact step and its own emission)
-                if (vo && mlo == 12u) mlo += first_diff16(ld128(src + pos + 16u), ld128(src + old + 16u));
-                if (vo && mlo == 28u) mlo += first_diff16(ld128(src + pos + 32u), ld128(src + old + 32u));
+                if (vo && mlo == 12u) {                       // (all four loads in one round trip)
+                    const u32x4 f2 = ld128(src + pos + 16u), c2 = ld128(src + old + 16u);
+                    const u32x4 f3 = ld128(src + pos + 32u), c3 = ld128(src + old + 32u);
+                    const uint32_t d2 = first_diff16(f2, c2);
+                    mlo += d2 == 16u ? 16u + first_diff16(f3, c3) : d2;
+                }
                 const bool single = grp == lane_bit;
                 const bool oldfast = vo && mlo < 44u;         // result against the pre-window value is complete in registers
                 const uint64_t wrmask = ballot(wr);
