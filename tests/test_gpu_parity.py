@@ -181,3 +181,39 @@ def test_rank4_entry_points(zl, oracle, gpu):
         except zl.Lz4Error as e:
             got = e.code
         assert got == want, stream
+
+
+def test_decoder_batch_path_malformed_and_capacity_stress(zl, oracle, gpu):
+    """The wave decoder's batch path only runs on streams of >= 68 bytes with output room to spare, i.e. not on the
+    small cases above.  Text blocks of 4..64 KiB (fast, accelerated and HC streams): several hundred corruptions
+    (bit flips, byte replacements, 0x00 / 0xFF runs that fake offsets of 0 and 255-chains), truncations and a
+    capacity sweep around the exact size.  Status must equal the oracle's; on success the bytes too."""
+    rng = np.random.default_rng(20240607)
+    blocks = [bytes(dg.text_bytes(n, 77 + i)) for i, n in enumerate((4096, 20000, 65536, 65536))]
+    blocks.append(bytes(dg.mixed_bytes(65536, 5)))
+    names, comp, caps = [], [], []
+    for bi, b in enumerate(blocks):
+        streams = [oracle.compress_default(b), oracle.compress_fast(b, 7), oracle.compress_hc(b, 9)]
+        for si, c in enumerate(streams):
+            n = len(b)
+            for cap in (n, n + 1, n + 31, n + 32, n - 1, n - 4, n - 17, n - 31, n - 32, n - 33, n - 100, n // 2,
+                        int(rng.integers(1, n)), int(rng.integers(1, n))):
+                names.append("b%d/s%d/cap%d" % (bi, si, cap)); comp.append(c); caps.append(cap)
+            for k in range(24):
+                m = bytearray(c)
+                pos = int(rng.integers(0, len(m)))
+                kind = k % 6
+                if kind == 0: m[pos] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1: m[pos] = int(rng.integers(0, 256))
+                elif kind == 2: m[pos:pos + 2] = b"\x00\x00"              # an offset of 0 somewhere
+                elif kind == 3: m[pos:pos + 4] = b"\xff\xff\xff\xff"      # 255-chains / huge lengths
+                elif kind == 4: m[pos] = 0xF0 | (m[pos] & 15)             # literal-length extension
+                else: m[pos] = (m[pos] & 0xF0) | 15                       # match-length extension
+                names.append("b%d/s%d/corrupt%d@%d" % (bi, si, kind, pos)); comp.append(bytes(m)); caps.append(n)
+            for k in range(6):
+                cut = int(rng.integers(1, len(c)))
+                names.append("b%d/s%d/trunc%d" % (bi, si, cut)); comp.append(c[:cut]); caps.append(n)
+    want = [oracle.decompress_safe(c, cap) for c, cap in zip(comp, caps)]
+    assert sum(isinstance(w, int) for w in want) > 100 and sum(not isinstance(w, int) for w in want) > 50
+    got = gh.decompress(zl, comp, caps, gpu)
+    _cmp(names, got, want)
