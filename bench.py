@@ -367,6 +367,10 @@ def main():
                                     "unit": "GB/s", "frac": algo / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "traffic": traffic.get("decompress"), "avg_launch_ms": td_ms},
         }
+        # achieved fraction of HBM bandwidth from the FETCH/WRITE counters themselves (BASELINE.json's "HBM-% achieved")
+        for key, ms in (("roofline", dom_ms), ("roofline_decompress", td_ms)):
+            tr = res[key]["traffic"]
+            res[key]["traffic_frac"] = None if tr is None else tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if frame_mode:
             res["roofline"]["note"] = ("frame calls = descriptor + batch compress + plan + scatter kernels plus "
                                        "hipMalloc/hipFree of the slot arena inside the call; avg_launch_ms is the whole call")

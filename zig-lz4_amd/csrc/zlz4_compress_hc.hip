@@ -179,19 +179,36 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
         u32x4 p16 = {pattern, 0, 0, 0};
         if (wide) p16 = ld128(src + p);
         const uint32_t avail = limit - p;                        // lz4Count stops at iHighLimit
-        while (m > 0 && nb > 0) {                                // :571
+        if (wide) {
+            // Straight-line loop body (selects instead of nested branches: every divergent `if` costs scalar
+            // exec-mask instructions, and the scalar unit is what bounds this kernel).  Same exits and the same
+            // final m as the reference loop: candidate out of range (:573), attempts used up (:571), a match
+            // longer than nbAttempts (:613), end of chain (:620).
+            bool go = m <= p && (p - m) <= kMaxDist;             // :571 (m > 0, nb > 0 here), :573
+            while (go) {
+                nb -= 1;                                         // :577
+                const T lk = link[m];                            // chain link, fetched together with the candidate bytes
+                const uint32_t d = first_diff16_sel(p16, ld128(src + m));   // m < p, so m + 16 <= n too
+                int32_t mlt = d >= kMinMatch ? (int32_t)(d < avail ? d : avail) : 0;   // :586, :588
+                if (d == 16u && avail > 16u) mlt = (int32_t)(16u + lz4_count(src, p + 16u, m + 16u, limit));
+                mlt = m >= lowest ? mlt : 0;                     // :579
+                // back == 0: `ip > iLowLimit` is false (:596)
+                const bool better = mlt > best_len;              // :607 (mlt == 0 when the 4 bytes differ)
+                best_len = better ? mlt : best_len;
+                best_off = better ? p - m : best_off;
+                const uint32_t delta = Links<T>::delta(m, lk);   // :619
+                const bool stop = (better && mlt > max_attempts) || delta == 0 || delta > m;   // :613, :620
+                m = stop ? m : m - delta;                        // :621
+                go = !stop && nb > 0 && m > 0 && (p - m) <= kMaxDist;
+            }
+        } else
+        while (m > 0 && nb > 0) {                                // :571 (the last <= 4 positions of a block)
             if (m > p || (p - m) > kMaxDist) break;              // :573
             nb -= 1;                                             // :577
-            const T lk = link[m];                                // chain link, fetched together with the candidate bytes
+            const T lk = link[m];
             if (m >= lowest) {                                   // :579
                 int32_t mlt = 0;
-                if (wide) {
-                    const uint32_t d = first_diff16(p16, ld128(src + m));    // m < p, so m + 16 <= n too
-                    if (d >= kMinMatch) {                        // :586
-                        if (d == 16u && avail > 16u) mlt = (int32_t)(16u + lz4_count(src, p + 16u, m + 16u, limit));
-                        else mlt = (int32_t)(d < avail ? d : avail);
-                    }
-                } else if (ld32(src + m) == pattern) {           // :586 (the last <= 4 positions of a block)
+                if (ld32(src + m) == pattern) {                  // :586
                     mlt = (int32_t)(kMinMatch + lz4_count(src, p + kMinMatch, m + kMinMatch, limit));
                 }
                 // back == 0: `ip > iLowLimit` is false (:596)

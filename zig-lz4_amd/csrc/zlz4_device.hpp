@@ -51,6 +51,17 @@ __device__ __forceinline__ uint32_t first_diff16(u32x4 a, u32x4 b) {
     return 16u;
 }
 
+// the same with selects only (no divergent branches: for per-lane loops whose cost is scalar exec-mask handling)
+__device__ __forceinline__ uint32_t first_diff16_sel(u32x4 a, u32x4 b) {
+    const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+    const uint32_t lo = x0 ? x0 : x1, hi = x2 ? x2 : x3;
+    const uint32_t blo = x0 ? 0u : 4u, bhi = x2 ? 8u : 12u;
+    const bool in_lo = (x0 | x1) != 0;
+    const uint32_t x = in_lo ? lo : hi;
+    const uint32_t base = in_lo ? blo : bhi;
+    return x ? base + ((uint32_t)__builtin_ctz(x) >> 3) : 16u;
+}
+
 // Wave-cooperative forward copy of n bytes (n wave-uniform).  Chunks of 1 KiB
 // (16 B per lane, unaligned dwordx4) in increasing address order, then a byte
 // tail.  Safe for dst/src in the same buffer when dst - src >= 1024 or the
