@@ -197,9 +197,10 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
                 best_len = better ? mlt : best_len;
                 best_off = better ? p - m : best_off;
                 const uint32_t delta = Links<T>::delta(m, lk);   // :619
-                const bool stop = (better && mlt > max_attempts) || delta == 0 || delta > m;   // :613, :620
+                // (bitwise, not short-circuit: no branches)
+                const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > m);   // :613, :620
                 m = stop ? m : m - delta;                        // :621
-                go = !stop && nb > 0 && m > 0 && (p - m) <= kMaxDist;
+                go = (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0) & (int)((p - m) <= kMaxDist));
             }
         } else
         while (m > 0 && nb > 0) {                                // :571 (the last <= 4 positions of a block)
