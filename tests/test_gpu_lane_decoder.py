@@ -1,6 +1,6 @@
-"""The one-lane-per-block decoder (used for batches >= 16384 blocks) through the same parity tests as the
-wave-per-block decoder: a child pytest process with ZLZ4_DECOMP_LANE_MIN=1 (the threshold is read once per
-process) runs every decompress / frame-decode test."""
+"""The one-lane-per-block decoder (the large-batch decoder before the wave decoder got its batch path; kept for
+comparison behind ZLZ4_DECOMP_LANE_MIN) through the same parity tests as the default decoder: a child pytest process
+with ZLZ4_DECOMP_LANE_MIN=1 (the threshold is read once per process) runs every decompress / frame-decode test."""
 import os
 import subprocess
 import sys
@@ -21,3 +21,4 @@ def test_lane_decoder_passes_the_decoder_parity_tests(gpu):
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+

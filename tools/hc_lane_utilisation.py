@@ -1,0 +1,20 @@
+"""Diagnostic (-DZLZ4_STAMPS build): how many of the 64 lanes of the HC search kernel are still walking their chain
+per loop trip.  Usage: ZLZ4_AMD_LIB=zig-lz4_amd/libzlz4_amd_stamps.so python tools/hc_lane_utilisation.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, bench, zig_lz4_amd as zl
+dev = torch.device("cuda:0"); nblocks = 512; block = 65536
+inp = bench.make_device_blocks("text", nblocks, block, dev, seed=1)
+slot = (zl.compressBound(block) + 15) // 16 * 16
+ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
+in_len = torch.full((nblocks,), block, dtype=torch.int32, device=dev)
+cap = torch.full((nblocks,), slot, dtype=torch.int32, device=dev)
+comp = torch.empty(nblocks * slot, dtype=torch.uint8, device=dev)
+res = torch.empty(nblocks, dtype=torch.int64, device=dev)
+ws = torch.empty(zl.batch_compress_hc_workspace(nblocks, block), dtype=torch.uint8, device=dev)
+zl.batch_compress_hc(inp, ar * block, in_len, comp, ar * slot, cap, res, block, 9, ws)
+torch.cuda.synchronize()
+L = zl.lib(); buf = (C.c_ulonglong * 4)()
+L.zlz4_debug_read_hstamps(buf)
+print("lane steps %d  wave-iteration lane slots %d  utilisation %.3f  steps/position %.1f" % (buf[0], buf[1], buf[0] / max(1, buf[1]), buf[0] / (nblocks * block)))

@@ -28,6 +28,13 @@
 
 #include "zlz4_device.hpp"
 
+#ifdef ZLZ4_STAMPS
+__device__ unsigned long long g_zlz4_hstamps[4];
+extern "C" int zlz4_debug_read_hstamps(unsigned long long *out4) {
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_zlz4_hstamps), 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -7;
+}
+#endif
+
 namespace zlz4 {
 
 constexpr uint32_t kHcHashLog = 15;                 // src/lz4hc.zig:37
@@ -146,6 +153,41 @@ __device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, ui
 // One lane per position, each lane runs its own chain walk.  (A per-wave work-queue variant that re-assigns
 // finished lanes and tests one candidate per loop iteration with 16-byte compares was measured 15-40 % SLOWER
 // on MI355X: this kernel is bound by gather throughput, not by divergence -- see DESIGN.md section 6.)
+// the patternAnalysis step that follows the chain walk (:626-676); m = where the walk stopped
+template <typename T>
+__device__ __forceinline__ void hc_pattern_step(const uint8_t *src, const T *link, uint32_t p, uint32_t m, uint32_t pattern,
+                                                uint32_t lowest, uint32_t limit, int32_t &best_len, uint32_t &best_off) {
+    {
+        // (:626 patternAnalysis is checked by the caller; the register test of :629-631 goes first so that the link is
+        //  only loaded for a four-equal-bytes pattern -- both conditions are pure)
+        if (best_len > 0 && ((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {
+            const uint32_t delta = Links<T>::delta(m, link[m]);  // :627 (m == 0 -> link[0] -> delta 0)
+            if (delta == 1) {
+                const uint32_t src_pat_len = count_pattern(src, p + 4u, limit, pattern) + 4u;   // :633
+                const uint32_t cand = m - 1u;                    // :636
+                if (cand >= lowest) {                            // :637 (dictIdx == 0)
+                    if (ld32(src + cand) == pattern) {           // :644
+                        const uint32_t fwd_len = count_pattern(src, cand + 4u, limit, pattern) + 4u;   // :646
+                        const uint32_t back_len = reverse_count_pattern(src, cand, pattern);           // :650
+                        uint32_t lo = cand - back_len;           // :653
+                        if (lo < lowest) lo = lowest;
+                        const uint32_t lim_back = cand - lo;
+                        const uint32_t seg_len = lim_back + fwd_len;                                   // :654
+                        const int32_t max_ml = (int32_t)(seg_len < src_pat_len ? seg_len : src_pat_len);   // :658
+                        uint32_t new_m;
+                        if (seg_len >= src_pat_len && fwd_len <= src_pat_len) new_m = cand + fwd_len - src_pat_len;   // :660-662
+                        else new_m = cand - lim_back;            // :665
+                        if (max_ml > best_len && (p - new_m) <= kMaxDist) {   // :669
+                            best_len = max_ml;
+                            best_off = p - new_m;
+                        }
+                    }
+                }
+            }
+        }
+        }
+}
+
 template <typename T, typename R>   // R = packed result: u32 (len | off << 16) for T = u16, u64 (len | off << 32) otherwise
 __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d_in,
                                                     const uint64_t *__restrict__ d_in_off,
@@ -185,7 +227,13 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
             // final m as the reference loop: candidate out of range (:573), attempts used up (:571), a match
             // longer than nbAttempts (:613), end of chain (:620).
             bool go = m <= p && (p - m) <= kMaxDist;             // :571 (m > 0, nb > 0 here), :573
+#ifdef ZLZ4_STAMPS
+            unsigned long long my_steps = 0, wave_iters = 0;
+            while (__ballot(go)) { wave_iters++; if (go) {
+                my_steps++;
+#else
             while (go) {
+#endif
                 nb -= 1;                                         // :577
                 const T lk = link[m];                            // chain link, fetched together with the candidate bytes
                 const uint32_t d = first_diff16_sel(p16, ld128(src + m));   // m < p, so m + 16 <= n too
@@ -202,6 +250,11 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
                 m = stop ? m : m - delta;                        // :621
                 go = (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0) & (int)((p - m) <= kMaxDist));
             }
+#ifdef ZLZ4_STAMPS
+            }
+            atomicAdd(&g_zlz4_hstamps[0], my_steps);
+            if ((threadIdx.x & 63u) == 0) atomicAdd(&g_zlz4_hstamps[1], wave_iters * 64ull);
+#endif
         } else
         while (m > 0 && nb > 0) {                                // :571 (the last <= 4 positions of a block)
             if (m > p || (p - m) > kMaxDist) break;              // :573
@@ -223,31 +276,7 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
             if (delta == 0 || delta > m) break;                  // :620
             m -= delta;                                          // :621
         }
-        if (pattern_analysis && best_len > 0) {                  // :626
-            const uint32_t delta = Links<T>::delta(m, link[m]);  // :627 (m == 0 -> link[0] -> delta 0)
-            if (delta == 1 && ((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {   // :629-631
-                const uint32_t src_pat_len = count_pattern(src, p + 4u, limit, pattern) + 4u;   // :633
-                const uint32_t cand = m - 1u;                    // :636
-                if (cand >= lowest) {                            // :637 (dictIdx == 0)
-                    if (ld32(src + cand) == pattern) {           // :644
-                        const uint32_t fwd_len = count_pattern(src, cand + 4u, limit, pattern) + 4u;   // :646
-                        const uint32_t back_len = reverse_count_pattern(src, cand, pattern);           // :650
-                        uint32_t lo = cand - back_len;           // :653
-                        if (lo < lowest) lo = lowest;
-                        const uint32_t lim_back = cand - lo;
-                        const uint32_t seg_len = lim_back + fwd_len;                                   // :654
-                        const int32_t max_ml = (int32_t)(seg_len < src_pat_len ? seg_len : src_pat_len);   // :658
-                        uint32_t new_m;
-                        if (seg_len >= src_pat_len && fwd_len <= src_pat_len) new_m = cand + fwd_len - src_pat_len;   // :660-662
-                        else new_m = cand - lim_back;            // :665
-                        if (max_ml > best_len && (p - new_m) <= kMaxDist) {   // :669
-                            best_len = max_ml;
-                            best_off = p - new_m;
-                        }
-                    }
-                }
-            }
-        }
+        if (pattern_analysis) hc_pattern_step<T>(src, link, p, m, pattern, lowest, limit, best_len, best_off);
     }
     R r;
     if (sizeof(R) == 4) r = (R)((uint32_t)best_len | (best_off << 16));
@@ -362,6 +391,11 @@ extern "C" size_t zlz4_hc_opt_workspace_bytes(uint32_t chunk_blocks);
 namespace zlz4 {
 
 // K1 + K2 (+ K3 for the greedy levels, or the price-based parse for levels 10-12) in rounds of `chunk` blocks
+// (A per-wavefront work-queue form of K2 -- a lane that finishes its chain takes the next unassigned position, first
+//  and chain steps sharing the same two load instructions -- raises the share of busy lanes from 23 % to ~90 % and was
+//  bit-exact, but ran 2.3x SLOWER on MI355X (938 vs 414 ms on configs[3]): neighbouring positions walk neighbouring
+//  chains, so the lock-step kernel's 64 gathers of a trip fall into a few cache lines, while the queue's lanes drift
+//  apart and every gather becomes a random access.  Measured twice in round 1; do not try a third time.)
 template <typename T, typename R>
 int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                       uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, int64_t *d_result,
