@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
     const uint64_t *__restrict__ d_out_off, const uint32_t *__restrict__ d_out_cap,
-    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration) {
+    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration, uint32_t tune_restart) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_wg = threadIdx.x >> 6;
@@ -150,6 +150,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
         STAMP_DECL
         STAMP(0);   // table init
 
+        // a window that has produced a match hands over to the next one once the search front passes this lane
+        const uint32_t restart_lane = rfl(tune_restart);
         uint32_t guard = 0;      // every round of this loop consumes at least one input byte
         // forward bytes of the next window, loaded as soon as its anchor is known (before the emission and the table
         // fix-up of the current window, which hide the load)
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                             "1:\n\t"
                             "s_cmp_gt_u32 %[f], 63\n\t"
                             "s_cbranch_scc1 3f\n\t"
-                            "s_cmp_lt_u32 %[f], 49\n\t"
+                            "s_cmp_lt_u32 %[f], %[rs]\n\t"
                             "s_cbranch_scc1 2f\n\t"
                             "s_cmp_eq_u32 %[nseq], 0\n\t"
                             "s_cbranch_scc0 3f\n"
@@ -339,11 +341,11 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                             "s_branch 1b\n"
                             "3:\n"
                             : [f] "+s"(f), [a] "+s"(a), [nseq] "+s"(nseq), [mm] "+s"(mm_run), [pk] "=&s"(t_pk), [j] "=&s"(t_j)
-                            : [PK] "v"(PK)
+                            : [PK] "v"(PK), [rs] "s"(restart_lane)
                             : "scc");
                     }
                     STAMP(8);
-                    if (f >= 64u || (f >= 49u && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
+                    if (f >= 64u || (f >= restart_lane && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
                         if (nseq == 0u) continue_generic = true;    // every lane probed, no match
                         break;
                     }
@@ -605,16 +607,20 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
     static const uint32_t lds_pad = [] { const char *e = getenv("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
     // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
     static const uint32_t tune_wpw = [] { const char *e = getenv("ZLZ4_TUNE_WPW"); return e ? (uint32_t)atoi(e) : 0u; }();
+    // lane at which a window that already holds a match stops and hands over to the next window (any value 1..64 gives
+    // the same bytes; it trades sequences per window against re-probed lanes)
+    static const uint32_t restart = [] { const char *e = getenv("ZLZ4_TUNE_RESTART"); const uint32_t v = e ? (uint32_t)atoi(e) : 64u;
+                                         return v >= 1u && v <= 64u ? v : 64u; }();
     if (max_in_len <= 65536u + 11u) {
         const uint32_t wpw = (tune_wpw == 1 || tune_wpw == 2) ? tune_wpw : 4;   // 4 x 8 KiB = 32 KiB LDS per workgroup -> 5 workgroups (20 waves) per CU
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint16_t) + lds_pad, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration);
+                           d_out_cap, d_result, nblocks, acceleration, restart);
     } else {
         const uint32_t wpw = 2;   // 2 x 16 KiB = 32 KiB LDS per workgroup -> 5 workgroups (10 waves) per CU
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint32_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint32_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration);
+                           d_out_cap, d_result, nblocks, acceleration, restart);
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
