@@ -240,6 +240,14 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 // fast-run step of a search that starts at lane f, precomputed for every f: PK = j | (v_end[j] << 6) when
                 // the search ends with the in-register match at j = J[f] (no slow lane first, j's hash unique in the
                 // window), else ~0.  (Exact steps only rewrite v_end of lanes the search has already passed.)
+                // for the exact step: XP = first lane >= f that can match at all (min(J, S), 64 = none) | its nsing bit << 7;
+                // Q = what a probe finds against the pre-window value: valid (:345-348) | matched extension bytes << 1
+                uint32_t XP, Q;
+                {
+                    const uint32_t xm = J < S ? J : S;
+                    XP = xm | ((uint32_t)((nsing >> (xm & 63u)) & 1ull) << 7);
+                    Q = (vo ? 1u : 0u) | (mlo << 1);
+                }
                 uint32_t PK;
                 {
                     const uint32_t jc = J & 63u;
@@ -351,8 +359,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     }
 
                     // ---- exact step for the probe at the first lane >= f that can match at all ----
-                    const uint32_t j0 = rdlane(J, f), s0 = rdlane(S, f);
-                    const uint32_t x = s0 < j0 ? s0 : j0;
+                    const uint32_t xp = rdlane(XP, f);
+                    const uint32_t x = xp & 127u;
                     if (x >= 64u) {
                         if (nseq == 0u) continue_generic = true;   // the search goes on past the window -> generic batches
                         // else: restart a fresh window at the current anchor (its lanes > a are re-probed there)
@@ -361,32 +369,43 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     // earlier put()s of this window with the same hash (only lanes of duplicate-hash groups can have one):
                     // every lane below x that is not strictly inside a match has been put
                     uint64_t pm = 0;
-                    if ((nsing >> x) & 1ull) {
+                    if (xp >> 7) {
                         const uint64_t grp_x = (uint64_t)rdlane((uint32_t)grp, x) | ((uint64_t)rdlane((uint32_t)(grp >> 32), x) << 32);
                         pm = grp_x & wrmask & ~covered_now() & ((1ull << x) - 1ull);
                     }
-                    uint32_t m_cand, cy, cz, cw;
-                    bool ok;
-                    if (pm) {
-                        const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
-                        ok = rdlane(fwd.x, pr) == rdlane(fwd.x, x);          // :348 (other tests hold in-window)
-                        m_cand = A + pr;
-                        cy = rdlane(fwd.y, pr); cz = rdlane(fwd.z, pr); cw = rdlane(fwd.w, pr);
-                    } else {
-                        ok = rdlane((uint32_t)vo, x) != 0;
-                        m_cand = rdlane(old, x);
-                        cy = rdlane(cold.y, x); cz = rdlane(cold.z, x); cw = rdlane(cold.w, x);
-                    }
-                    if (!ok) { STAMP_COUNT(19); STAMP(9); f = x + 1u; continue; }      // probed, put, no match: next probe
-                    STAMP_COUNT(18);
                     const uint32_t j = x;
                     const uint32_t m_pos = A + j;
-                    const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ cz) << 32) | (rdlane(fwd.y, j) ^ cy);
-                    const uint32_t xb = rdlane(fwd.w, j) ^ cw;
-                    uint32_t mlen;
-                    if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
-                    else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
-                    else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
+                    uint32_t m_cand, mlen;
+                    if (pm) {
+                        // the probe reads the nearest earlier put of the window
+                        const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
+                        if (rdlane(fwd.x, pr) != rdlane(fwd.x, x)) { STAMP_COUNT(19); STAMP(9); f = x + 1u; continue; }   // :348
+                        STAMP_COUNT(18);
+                        m_cand = A + pr;
+                        const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ rdlane(fwd.z, pr)) << 32) | (rdlane(fwd.y, j) ^ rdlane(fwd.y, pr));
+                        const uint32_t xb = rdlane(fwd.w, j) ^ rdlane(fwd.w, pr);
+                        if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
+                        else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
+                        else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
+                    } else {
+                        // the probe reads the pre-window value: the vector code has already compared up to 48 bytes
+                        const uint32_t q = rdlane(Q, x);
+                        if (!(q & 1u)) { STAMP_COUNT(19); STAMP(9); f = x + 1u; continue; }      // probed, put, no match: next probe
+                        STAMP_COUNT(18);
+                        mlen = q >> 1;
+                        if (mlen < 44u && !tight) {
+                            // v_end / mlo_e / off_e of lane j already describe this sequence: it just joins the run
+                            mm_run |= 1ull << j;
+                            nseq++;
+                            a = j + kMinMatch + mlen;
+                            STAMP(9);
+                            if (a >= 64u) break;                            // the next window inserts it as its lane 0
+                            f = a + 1u;
+                            continue;
+                        }
+                        m_cand = rdlane(old, x);
+                        if (mlen >= 44u) mlen = extend_match(src, m_pos, m_cand, 44u, match_limit, src_size, lane);
+                    }
                     const uint32_t lit = j - a;
                     const uint32_t offset = m_pos - m_cand;
                     const uint32_t e = j + kMinMatch + mlen;                // lane of the new anchor (may be >= 64)
