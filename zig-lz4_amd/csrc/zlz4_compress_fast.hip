@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256) void k_compress_fast(
             // value.  At the end lanes not in `ins` put their old value back.
             // =====================================================================================
             if (accel == 1u && F0 == anchor + 1u && (has_ins || anchor == 0u) && (uint64_t)anchor + 192u < L) {
+              bool moved = false;           // the last window of the run advanced the anchor ...
+              bool to_generic = false;      // ... or handed its search over to the generic path
+              for (;;) {                    // consecutive windows: the next one starts without re-deriving the entry test
                 const uint32_t A = anchor;
                 const uint32_t pos = A + lane;
                 const bool wr = has_ins || lane > 0;                    // position 0 is never inserted (Q1)
@@ -208,18 +211,19 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const bool vo = old_ok && cold.x == fwd.x;
                 uint32_t mlo;
                 {
+                    // selects only (a nested ?: chain compiles to exec-mask branches, i.e. scalar instructions)
                     const uint32_t x1 = fwd.y ^ cold.y, x2 = fwd.z ^ cold.z, x3 = fwd.w ^ cold.w;
-                    mlo = x1 ? (uint32_t)__builtin_ctz(x1) >> 3
-                             : (x2 ? 4u + ((uint32_t)__builtin_ctz(x2) >> 3)
-                                   : (x3 ? 8u + ((uint32_t)__builtin_ctz(x3) >> 3) : 12u));
+                    const uint32_t xs = x1 ? x1 : (x2 ? x2 : x3);
+                    const uint32_t xbase = x1 ? 0u : (x2 ? 4u : 8u);
+                    mlo = xs ? xbase + ((uint32_t)__builtin_ctz(xs) >> 3) : 12u;
                 }
                 // second level: the few lanes whose 16 bytes all match compare 16 more (matches of 16..31 bytes are a
                 // fifth of all sequences on text; without this each of them costs an exact step and its own emission)
                 if (vo && mlo == 12u) {                       // (all four loads in one round trip)
                     const u32x4 f2 = ld128(src + pos + 16u), c2 = ld128(src + old + 16u);
                     const u32x4 f3 = ld128(src + pos + 32u), c3 = ld128(src + old + 32u);
-                    const uint32_t d2 = first_diff16(f2, c2);
-                    mlo += d2 == 16u ? 16u + first_diff16(f3, c3) : d2;
+                    const uint32_t d2 = first_diff16_sel(f2, c2);
+                    mlo += d2 == 16u ? 16u + first_diff16_sel(f3, c3) : d2;
                 }
                 const bool single = grp == lane_bit;
                 const bool oldfast = vo && mlo < 44u;         // result against the pre-window value is complete in registers
@@ -445,7 +449,9 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     if (e >= 64u) break;                                    // the next window inserts it as its lane 0
                     f = e + 1u;
                 }
-                if (!continue_generic && !failed && a != 0u && (uint64_t)A + a + 192u < L) {
+                // (next_win implies everything the entry test above asks of the next round)
+                const bool next_win = !continue_generic && !failed && a != 0u && (uint64_t)A + a + 192u < L;
+                if (next_win) {
                     pf_anchor = A + a;
                     fwd_pf = ld128(src + pf_anchor + lane);
                 }
@@ -462,7 +468,18 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 if ((ins & lane_bit) && (grp & ins & ~lanes_below & ~lane_bit) == 0) table[h] = (T)pos;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 STAMP(5);
-                if (!continue_generic && anchor != A) {
+                moved = anchor != A;
+                to_generic = continue_generic;
+                if (next_win) {
+                    has_ins = true;
+                    F0 = anchor + 1u;
+                    if (++guard > src_size) { failed = true; break; }       // unreachable; never spin on the GPU
+                    continue;
+                }
+                break;
+              }
+                if (failed) break;
+                if (!to_generic && moved) {
                     if (anchor < L) { has_ins = true; F0 = anchor + 1u; }
                     else { has_ins = false; F0 = L; }
                     continue;
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 // continue_generic: same search, next probe index 63 (lane 0 of the next batch is position F0 + 63).
                 // (anchor == A without continue_generic cannot happen; if it ever did, the generic path below restarts
                 //  the search from F0 -- the table then holds exactly the anchor's put -- and always makes progress.)
-                if (continue_generic) ub = 63;
+                if (to_generic) ub = 63;
             }
 
             // =====================================================================================
