@@ -58,6 +58,8 @@ def lib():
         L.zo_compress_dest_size.argtypes = [u8p, u8p, sz, C.POINTER(C.c_size_t)]
         L.zo_decompress_safe_partial.restype = i64
         L.zo_decompress_safe_partial.argtypes = [u8p, sz, u8p, sz, sz]
+        L.zo_hc_reference_ub.restype = i64
+        L.zo_hc_reference_ub.argtypes = [C.c_int]
         L.zo_xxh32.restype = C.c_uint32
         L.zo_xxh32.argtypes = [u8p, sz, C.c_uint32]
         L.zo_compress_frame_bound.restype = sz
@@ -107,6 +109,11 @@ def compress_fast(src, accel, cap=None):
 def compress_hc(src, level, cap=None):
     cap = compress_bound(len(src)) if cap is None else cap
     return _call(lib().zo_compress_hc, src, cap, level)
+
+
+def hc_reference_ub(reset=True):
+    """number of times compress_hc met the reference's u32 underflow (lz4hc.zig:636) since the last reset"""
+    return lib().zo_hc_reference_ub(1 if reset else 0)
 
 
 def decompress_safe(src, cap):

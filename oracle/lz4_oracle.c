@@ -12,6 +12,10 @@
  */
 #include "lz4_oracle.h"
 
+/* number of times compressHC hit the reference's `matchIndex - 1` underflow (see insertAndGetWiderMatch) */
+int64_t zo_hc_reference_ub_count = 0;
+int64_t zo_hc_reference_ub(int reset) { const int64_t v = zo_hc_reference_ub_count; if (reset) zo_hc_reference_ub_count = 0; return v; }
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -587,6 +591,15 @@ static hc_match insertAndGetWiderMatch(hc_ctx *ctx, const uint8_t *ip, const uin
 
     if (patternAnalysis && result.len > 0) {                                             /* :626 */
         const uint16_t delta = ctx->chainTable[matchIndex & LZ4HC_MAXD_MASK];            /* :627 */
+        /* Reference defect (found by tools/fuzz_parity.py): when the walk ended at matchIndex == 0 -- the normal end
+         * of a chain -- chainTable[0] is the slot of position 65536 as well (index & 0xFFFF), so on inputs longer than
+         * 64 KiB it can hold 1; with a repetitive pattern :636 then computes `matchIndex - 1` on a u32 zero: a
+         * panic in Zig's safe build modes, a wild read (this restatement used to SEGV here) in ReleaseFast.  The
+         * reference has no defined output for such an input.  The restatement records the event and skips the
+         * branch, which is what the HIP path does by construction (its link of position 0 is 0). */
+        if (delta == 1 && matchIndex == 0 && isRepetitivePattern(pattern)) {
+            zo_hc_reference_ub_count += 1;
+        } else
         if (delta == 1) {                                                                /* :629 */
             if (isRepetitivePattern(pattern)) {                                          /* :631 */
                 const size_t srcPatternLength = countPattern(ip + 4, iHighLimit, pattern) + 4;   /* :633 */

@@ -85,6 +85,10 @@ int64_t zo_decompress_safe_partial(const uint8_t *src, size_t n, uint8_t *dst, s
 int64_t zo_compress_hc(const uint8_t *src, size_t n, uint8_t *dst,
                        size_t cap, int32_t level);                     /* lz4hc.zig:1440-1453 */
 
+/* how often compressHC met the reference's u32 underflow at lz4hc.zig:636 since the last reset (inputs > 64 KiB,
+ * levels 9-12; the reference has no defined output there, see lz4_oracle.c) */
+int64_t zo_hc_reference_ub(int reset);
+
 uint32_t zo_xxh32(const uint8_t *p, size_t n, uint32_t seed);          /* std.hash.XxHash32 */
 
 size_t  zo_compress_frame_bound(size_t n, const zo_prefs *prefs);      /* lz4f.zig:274-301 */
