@@ -534,7 +534,8 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
                            d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
         return hipGetLastError() == hipSuccess ? 0 : -7;
     }
-    const uint32_t waves_per_wg = 4;
+    static const uint32_t waves_per_wg = [] { const char *e = getenv("ZLZ4_DECOMP_WPW"); const uint32_t v = e ? (uint32_t)atoi(e) : 4u;
+                                              return (v == 1u || v == 2u || v == 4u) ? v : 4u; }();
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
     // experiment knob: dynamic LDS per workgroup only to limit the number of resident wavefronts per CU
     static const uint32_t dyn_lds = [] { const char *e = getenv("ZLZ4_DECOMP_LDS"); return e ? (uint32_t)atoll(e) : 0u; }();
