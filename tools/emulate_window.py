@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Lane-level Python emulation of k_compress_fast's window path + generic path (debug aid).
-Mirrors zig-lz4_amd/csrc/zlz4_compress_fast.hip statement by statement so logic bugs can be found on CPU."""
+Mirrors the window logic of zig-lz4_amd/csrc/zlz4_compress_fast.hip as it was when the window path was brought up
+(12-byte in-register compare, hand-over at lane 49, one flush per sequence): the later refinements of the kernel
+(48-byte compare levels, extension bytes in the run flush, precomputed fast-run steps, hand-over at lane 64) change
+how many sequences a window resolves and how they are emitted, not the bytes, so the emulator still produces the
+oracle's output and remains the place to try a change of the lane logic on the CPU first."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
