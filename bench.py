@@ -149,12 +149,20 @@ def main():
     if world != args.gpus:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     dist_on = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ZLZ4_BENCH_REHEARSE=1: rehearsal of the multi-rank control flow on a box with ONE GPU -- every rank uses cuda:0 and
+    # the barrier / max-reduction run over gloo (RCCL refuses two ranks on one device).  The value of such a run is
+    # meaningless; it only proves that the N > 1 path runs end to end.
+    rehearse = os.environ.get("ZLZ4_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if dist_on:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import zig_lz4_amd as zl     # raises if libzlz4_amd.so is missing: no fallback
     if not zl.device_available():
@@ -320,7 +328,7 @@ def main():
         td.barrier()
     elapsed = time.perf_counter() - t_start
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
     tc_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
