@@ -414,8 +414,12 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
                            d_in_len, d_link, stride, b0, nb);
-        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 255u) / 256u, nb), dim3(256), 0, stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0);
+        static const uint32_t k2_threads = [] { const char *e = getenv("ZLZ4_HC_SEARCH_THREADS"); const uint32_t v = e ? (uint32_t)atoi(e) : 64u;
+                                                return (v == 64u || v == 128u || v == 256u) ? v : 64u; }();
+        // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a workgroup
+        //  finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
+        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + k2_threads - 1u) / k2_threads, nb), dim3(k2_threads), 0, stream, d_in,
+                           d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0);
         if (optimal) {
             const int rc = zlz4_launch_hc_opt_parse(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
                                                     d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len);
