@@ -174,6 +174,38 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 //   do { pk = pkv[pos]; if (T + (pk >> 7) > room) break; R |= 1 << pos; T += pk >> 7; pos = pk & 127; } while (pos < 64);
                 uint32_t pos, T, wa, wpk, wt;
                 uint64_t R;
+                // Away from the end of the output (a batch never exceeds 21 x 335 bytes) the room test is not needed, and
+                // with "is the next token ok" folded into the word read for the current one a hop takes 7 instructions:
+                //   do { pk = pk2v[pos]; R |= 1 << pos; T += pk >> 8; next_ok = pk & 0x80; pos = pk & 127; } while (next_ok);
+                const uint64_t okm = ballot(ok);
+                const uint32_t pk2v = nxt | ((nxt < 64u && ((okm >> (nxt & 63u)) & 1ull)) ? 0x80u : 0u) | (ol << 8);
+                if (room0 >= 7100u && (okm & 1ull)) {
+                    asm volatile(
+                        "s_mov_b64 %[R], 0\n\t"
+                        "s_mov_b32 %[T], 0\n\t"
+                        "s_mov_b32 %[A], 0\n\t"
+                        "s_nop 3\n"
+                        "1:\n\t"
+                        "v_readlane_b32 %[pk], %[pkv], %[A]\n\t"
+                        "s_and_b32 %[B], %[pk], 0x7f\n\t"
+                        "s_bitset1_b64 %[R], %[A]\n\t"
+                        "s_lshr_b32 %[t], %[pk], 8\n\t"
+                        "s_add_u32 %[T], %[T], %[t]\n\t"
+                        "s_bitcmp1_b32 %[pk], 7\n\t"
+                        "s_cbranch_scc0 4f\n\t"
+                        "v_readlane_b32 %[pk], %[pkv], %[B]\n\t"
+                        "s_and_b32 %[A], %[pk], 0x7f\n\t"
+                        "s_bitset1_b64 %[R], %[B]\n\t"
+                        "s_lshr_b32 %[t], %[pk], 8\n\t"
+                        "s_add_u32 %[T], %[T], %[t]\n\t"
+                        "s_bitcmp1_b32 %[pk], 7\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_mov_b32 %[B], %[A]\n"
+                        "4:\n"
+                        : [R] "=&s"(R), [T] "=&s"(T), [A] "=&s"(wa), [B] "=&s"(pos), [pk] "=&s"(wpk), [t] "=&s"(wt)
+                        : [pkv] "v"(pk2v)
+                        : "scc");
+                } else
                 asm volatile(
                     "s_mov_b64 %[R], 0\n\t"
                     "s_mov_b32 %[T], 0\n\t"
