@@ -178,6 +178,9 @@ int32_t     zlz4_device_check(void);
 const char *zlz4_version_string(void);
 /* human-readable name of a ZLZ4_ERR_* / ZLZ4F_ERR_* code (mirrors the Zig error names) */
 const char *zlz4_error_name(int64_t code);
+/* The frame calls park their device scratch buffers (block slots, descriptors) in a small per-process cache instead of
+ * hipFree-ing them; this gives that memory back.  (No counterpart in the reference, which allocates nothing.) */
+void        zlz4_release_device_cache(void);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,7 @@ SYMBOLS = {
     "zlz4_device_check": (_I32, []),
     "zlz4_version_string": (C.c_char_p, []),
     "zlz4_error_name": (C.c_char_p, [_I64]),
+    "zlz4_release_device_cache": (None, []),
 }
 
 _lib = None

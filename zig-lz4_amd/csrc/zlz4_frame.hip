@@ -22,6 +22,9 @@
 #include <vector>
 
 #include "../../include/zlz4_amd.h"
+#include <mutex>
+#include <vector>
+
 #include "zlz4_device.hpp"
 
 extern "C" int zlz4_launch_decompress_safe(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
@@ -147,14 +150,61 @@ ParsedHeader parse_header(const uint8_t *src, size_t have) {
 }
 
 // ------------------------------------------------------------------ device buffers
+// Scratch memory of the frame calls (block slots, descriptors, plans).  hipMalloc / hipFree of a multi-GiB slot arena
+// cost milliseconds and hipFree synchronises the device, so freed buffers are parked in a small per-process cache
+// and handed out again (every frame call synchronises its stream before it returns, so a parked buffer is idle).
+// zlz4_release_device_cache() gives the memory back.
+namespace {
+struct ParkedBuf { void *p; size_t n; int dev; };
+std::mutex g_park_mutex;
+std::vector<ParkedBuf> g_parked;
+constexpr size_t kMaxParked = 12;
+}  // namespace
+
 struct DevBuf {
     void *p = nullptr;
-    explicit DevBuf(size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) p = nullptr; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t n = 0;
+    int dev = 0;
+    explicit DevBuf(size_t want) {
+        n = want ? want : 1;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        {
+            std::lock_guard<std::mutex> lock(g_park_mutex);
+            size_t best = g_parked.size();
+            for (size_t i = 0; i < g_parked.size(); i++)     // smallest parked buffer that fits and is not wastefully large
+                if (g_parked[i].dev == dev && g_parked[i].n >= n && g_parked[i].n / 2 <= n + (1u << 20) &&
+                    (best == g_parked.size() || g_parked[i].n < g_parked[best].n))
+                    best = i;
+            if (best != g_parked.size()) {
+                p = g_parked[best].p;
+                n = g_parked[best].n;
+                g_parked.erase(g_parked.begin() + (long)best);
+                return;
+            }
+        }
+        if (hipMalloc(&p, n) != hipSuccess) p = nullptr;
+    }
+    ~DevBuf() {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lock(g_park_mutex);
+            if (g_parked.size() < kMaxParked) { g_parked.push_back({p, n, dev}); return; }
+        }
+        (void)hipFree(p);
+    }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
+
+extern "C" void zlz4_release_device_cache(void) {
+    std::vector<ParkedBuf> take;
+    {
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        take.swap(g_parked);
+    }
+    for (const ParkedBuf &b : take) (void)hipFree(b.p);
+}
 
 // ------------------------------------------------------------------ compress-side kernels
 // block descriptors for the batch kernels: block i = src[i*bs, min(n, (i+1)*bs)) -> slot i
