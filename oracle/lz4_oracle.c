@@ -485,6 +485,10 @@ static int32_t countBack(const uint8_t *ip, const uint8_t *match, const uint8_t 
 /* src/lz4hc.zig:308-386; limit is always .limitedOutput on the compressHashChain path (:1025) */
 static int encodeSequence(const uint8_t **ip, uint8_t **op, const uint8_t **anchor,
                           int32_t matchLength, int32_t offset, int limitedOutput, uint8_t *oend) {
+    /* Reference defect #1 can hand this function an ip below the anchor: `ip - anchor` then
+     * underflows in the reference (panic in Zig's safe modes, a wild copy otherwise).  No defined output exists; the
+     * restatement reports OutputTooSmall, which is what the HIP path's 32-bit arithmetic makes of the same state. */
+    if (*ip < *anchor) { zo_hc_reference_ub_count += 1; return 1; }
     const size_t litLen = (size_t)(*ip - *anchor);                       /* :317 */
     if (limitedOutput) {                                                 /* :320-325 */
         const size_t needed = (litLen / 255) + litLen + (2 + 1 + LASTLITERALS);
@@ -990,6 +994,7 @@ static int64_t compressOptimal(hc_ctx *ctx, const uint8_t *src, size_t inputSize
         }
     }
     free(opt);
+    if (anchor > iend) { zo_hc_reference_ub_count += 1; return ZO_ERR_OUTPUT_TOO_SMALL; }   /* same defect: iend - anchor underflows */
     const size_t finalLiterals = (size_t)(iend - anchor);                /* :1362 */
     if (finalLiterals > 0) {
         if ((uintptr_t)op + finalLiterals + 1 > (uintptr_t)oend) return ZO_ERR_OUTPUT_TOO_SMALL;   /* :1364 */

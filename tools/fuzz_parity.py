@@ -67,7 +67,11 @@ def prepare(rounds, seed, path):
             store["r%d_in%d" % (r, i)] = np.frombuffer(b, dtype=np.uint8)
             store["r%d_f%d" % (r, i)] = np.frombuffer(oracle.compress_fast(b, accel), dtype=np.uint8)
             oracle.hc_reference_ub()
-            store["r%d_h%d" % (r, i)] = np.frombuffer(oracle.compress_hc(b, level), dtype=np.uint8)
+            h = oracle.compress_hc(b, level)
+            if isinstance(h, int):      # the lz4opt levels can run into the reference's defect #1: error code, no bytes
+                store["r%d_herr%d" % (r, i)] = np.array([h], dtype=np.int64)
+                h = b""
+            store["r%d_h%d" % (r, i)] = np.frombuffer(h, dtype=np.uint8)
             ub += 1 if oracle.hc_reference_ub() else 0
         print("prepared round %d (accel %d, level %d; %d inputs on which the reference's HC path has no defined output, "
               "see oracle/lz4_oracle.c)" % (r, accel, level, ub), flush=True)
@@ -93,6 +97,10 @@ def check(path):
             assert n == len(w) and data == w, "round %d fast accel %d item %d (size %d): GPU %d vs oracle %d bytes" % (r, accel, i, len(items[i]), n, len(w))
         got_h = gh.compress_hc(zl, items, dev, level)
         for i, ((n, data), w) in enumerate(zip(got_h, want_h)):
+            key = "r%d_herr%d" % (r, i)
+            if key in z.files:
+                assert n == int(z[key][0]), "round %d hc level %d item %d: GPU status %d vs oracle %d" % (r, level, i, n, int(z[key][0]))
+                continue
             assert n == len(w) and data == w, "round %d hc level %d item %d: GPU %d vs oracle %d bytes" % (r, level, i, n, len(w))
         hs = want_h if level < 10 else []      # the reference's lz4opt levels may emit undecodable streams
         got_d = gh.decompress(zl, want_f + hs, [len(b) for b in items] * (2 if hs else 1), dev)
