@@ -66,7 +66,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict__ d_in,
                                                         const uint64_t *__restrict__ d_in_off,
                                                         const uint32_t *__restrict__ d_in_len, T *__restrict__ d_link,
-                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks) {
+                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks,
+                                                        uint32_t *__restrict__ d_zero_res) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
     const uint32_t n = rfl(d_in_len[blk0 + b]);
     const uint32_t np = n_positions(n);
     T *link = d_link + (uint64_t)b * link_stride;
+    uint32_t *zero_res = d_zero_res ? d_zero_res + (uint64_t)b * link_stride : nullptr;   // K2s stores matches only
     typedef __attribute__((address_space(3))) volatile T lds_entry;   // (AS3-typed: ds_read / ds_write, not FLAT)
     lds_entry *table = (lds_entry *)lds_raw;
     {
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
         if (active) {
             const uint32_t prev = pred >= 0 ? base + (uint32_t)pred : old;
             link[q] = Links<T>::make(q, prev);          // :502-504 (clamp applied on read for T = u32)
+            if (zero_res) zero_res[q] = 0;
             if (grp != lane_bit && (grp & ~lanes_below & ~lane_bit) == 0) table[h] = (T)q;   // last of its group
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -154,8 +157,8 @@ __device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, ui
 // finished lanes and tests one candidate per loop iteration with 16-byte compares was measured 15-40 % SLOWER
 // on MI355X: this kernel is bound by gather throughput, not by divergence -- see DESIGN.md section 6.)
 // the patternAnalysis step that follows the chain walk (:626-676); m = where the walk stopped
-template <typename T>
-__device__ __forceinline__ void hc_pattern_step(const uint8_t *src, const T *link, uint32_t p, uint32_t m, uint32_t pattern,
+template <typename T, typename LinkPtr>
+__device__ __forceinline__ void hc_pattern_step(const uint8_t *src, LinkPtr link, uint32_t p, uint32_t m, uint32_t pattern,
                                                 uint32_t lowest, uint32_t limit, int32_t &best_len, uint32_t &best_off) {
     {
         // (:626 patternAnalysis is checked by the caller; the register test of :629-631 goes first so that the link is
@@ -276,12 +279,164 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
             if (delta == 0 || delta > m) break;                  // :620
             m -= delta;                                          // :621
         }
-        if (pattern_analysis) hc_pattern_step<T>(src, link, p, m, pattern, lowest, limit, best_len, best_off);
+        if (pattern_analysis) hc_pattern_step<T, const T *>(src, link, p, m, pattern, lowest, limit, best_len, best_off);
     }
     R r;
     if (sizeof(R) == 4) r = (R)((uint32_t)best_len | (best_off << 16));
     else r = (R)((uint64_t)(uint32_t)best_len | ((uint64_t)best_off << 32));
     d_res[(uint64_t)b * link_stride + p] = r;
+}
+
+
+// ------------------------------------------------------------------ K2s: parse-aware search (levels 3..9, blocks <= 64 KiB)
+// The greedy parse (:1009-1032) is a walk in a functional graph: next(p) = p + len(p) when the search at p finds a match,
+// p + 1 otherwise, and len(p) is a pure function of the input (see the file header).  Two walks that meet stay together,
+// and on real data walks that start a few bytes apart meet within a sequence or two (both matches end where the repeated
+// string ends; inside a literal run both visit every byte).  That makes the parse itself data-parallel:
+//   * the block is cut into start points every `seg_len` positions; a LANE takes the next start point from a counter in
+//     LDS and runs the reference's serial loop from there, as if the parse arrived at that byte (speculation);
+//   * every position a walk visits is marked in an LDS bitmap (atomic or); a walk ends at the first position that is
+//     already marked -- whoever marked it continues from there, so nothing is lost -- or at the end of the block.
+// The true parse (the walk from 0) is then the union of pieces that have all been searched, and K3 follows it through
+// res[] (zeroed by K1; only matches are stored).  Only visited positions are searched: 19 % of the positions and 5 % of
+// the chain steps of D-text at level 9 (the long chains belong to positions inside matches, which the parse never looks
+// at).  The block's chain links (u16 x 65536 = 128 KiB) stay in LDS for the whole search; one workgroup per block.
+// A loop trip is one memory round trip for every lane: either the next candidate of its chain (16-byte compare) or the
+// next 16 bytes of a candidate that matched so far.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+__global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restrict__ d_in,
+                                                         const uint64_t *__restrict__ d_in_off,
+                                                         const uint32_t *__restrict__ d_in_len,
+                                                         const uint16_t *__restrict__ d_link, uint64_t link_stride,
+                                                         uint32_t *__restrict__ d_res, uint32_t blk0, uint32_t nblocks,
+                                                         int32_t max_attempts, uint32_t max_in_len, uint32_t lk_bytes,
+                                                         uint32_t seg_len) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t n = d_in_len[blk0 + b];
+    if (n > max_in_len) return;                                  // K3 reports it; the workspace is sized by max_in_len
+    const uint32_t np = n_positions(n);
+    if (np == 0) return;
+    const uint8_t *src = d_in + d_in_off[blk0 + b];
+    uint32_t *res = d_res + (uint64_t)b * link_stride;
+    const lds_u16 *lk = (const lds_u16 *)lds_raw;
+    lds_u32 *bm = (lds_u32 *)(lds_raw + lk_bytes);               // visited bitmap, one bit per position
+    const uint32_t bm_words = (np + 31u) >> 5;
+    lds_u32 *next_seg = bm + bm_words;                           // start-point counter
+    {
+        const u32x4 *g4 = reinterpret_cast<const u32x4 *>(d_link + (uint64_t)b * link_stride);
+        u32x4 *l4 = reinterpret_cast<u32x4 *>(lds_raw);
+        const uint32_t n16 = (np * 2u + 15u) >> 4;
+        for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) l4[k] = g4[k];
+        for (uint32_t k = threadIdx.x; k <= bm_words; k += blockDim.x) bm[k] = 0;
+    }
+    __syncthreads();
+    const bool pattern_analysis = max_attempts > 128;            // :983
+    const uint32_t limit = n - kLastLiterals;                    // iHighLimit = matchlimit :989, :1011
+    const uint32_t nseg = (np + seg_len - 1u) / seg_len;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+
+    bool have = false, exhausted = false, in_chain = false;
+    uint32_t pos = 0, m = 0, off = 0, avail = 0, best_off = 0, pattern = 0;
+    int32_t nb = 0, best_len = (int32_t)kMinMatch - 1;
+    for (;;) {
+        // ---- start points for the lanes that have none
+        const uint64_t want = ballot(!have && !exhausted);
+        if (want) {
+            uint32_t base = 0;
+            if (lane == first_lane(want)) base = __hip_atomic_fetch_add(next_seg, (uint32_t)__popcll(want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = rdlane(base, first_lane(want));
+            if (!have && !exhausted) {
+                const uint32_t seg = base + (uint32_t)__popcll(want & lanes_below);
+                if (seg < nseg) { pos = seg * seg_len; have = true; in_chain = false; }
+                else exhausted = true;
+            }
+        }
+        if (!ballot(have)) break;
+        // ---- next position of the walk: stop at a marked one; positions whose hash was never seen before (no candidate,
+        //      :566-568) cost two LDS operations each, a few of them per trip
+        if (have && !in_chain) {
+            for (int it = 0; it < 3; ++it) {
+                if (pos >= np) { have = false; break; }
+                const uint32_t bit = 1u << (pos & 31u);
+                const uint32_t old = __hip_atomic_fetch_or(bm + (pos >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t l = lk[pos];
+                if (old & bit) { have = false; break; }
+                m = pos - l;                                     // :563 hashTable[hashPtr(ip)] (0 = none)
+                if (m == 0) { pos += 1; continue; }              // no match: res[pos] stays 0, :1013-1016
+                best_len = (int32_t)kMinMatch - 1;               // :560
+                best_off = 0;
+                nb = max_attempts;
+                if (pos + 16u > n) {
+                    // the last <= 4 searchable positions of a block: no room for 16-byte compares
+                    pattern = ld32(src + pos);
+                    while (m > 0 && nb > 0) {                    // :571 (m <= pos and pos - m <= 65535 hold for u16 links)
+                        nb -= 1;                                 // :577
+                        const uint32_t delta = lk[m];
+                        int32_t mlt = 0;
+                        if (ld32(src + m) == pattern)            // :586
+                            mlt = (int32_t)(kMinMatch + lz4_count(src, pos + kMinMatch, m + kMinMatch, limit));
+                        if (mlt > best_len) {                    // :607
+                            best_len = mlt;
+                            best_off = pos - m;
+                            if (mlt > max_attempts) break;       // :613
+                        }
+                        if (delta == 0 || delta > m) break;      // :620
+                        m -= delta;                              // :621
+                    }
+                    if (pattern_analysis)
+                        hc_pattern_step<uint16_t, const lds_u16 *>(src, lk, pos, m, pattern, 0u, limit, best_len, best_off);
+                    const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
+                    if (found) res[pos] = (uint32_t)best_len | (best_off << 16);
+                    pos += found ? (uint32_t)best_len : 1u;      // :1013-1016, :382
+                    continue;
+                }
+                avail = limit - pos;                             // lz4Count stops at iHighLimit
+                off = 0;
+                in_chain = true;
+                break;
+            }
+        }
+        // ---- one round trip of the chain walk :571-622
+        if (have && in_chain) {
+            const uint32_t delta = lk[m];                        // :619 chainTable[matchIndex]
+            const u32x4 a16 = ld128(src + pos + off);
+            const u32x4 b16 = ld128(src + m + off);              // m < pos, so m + off + 16 <= n too
+            if (off == 0) pattern = a16.x;
+            const uint32_t d = first_diff16_sel(a16, b16);
+            uint32_t total = off + d;
+            bool more = d == 16u && total < avail;
+            if (more && pos + total + 16u > n) {                 // no room for another 16-byte compare: finish by bytes
+                total += lz4_count(src, pos + total, m + total, limit);
+                more = false;
+            }
+            if (more) {
+                off = total;                                     // same candidate, next 16 bytes
+            } else {
+                nb -= 1;                                         // :577
+                const int32_t mlt = total >= kMinMatch ? (int32_t)(total < avail ? total : avail) : 0;   // :586, :588
+                const bool better = mlt > best_len;              // :607
+                best_len = better ? mlt : best_len;
+                best_off = better ? pos - m : best_off;
+                const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > m);   // :613, :620
+                m = stop ? m : m - delta;                        // :621
+                off = 0;
+                const bool go = (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0));
+                if (!go) {
+                    if (pattern_analysis)
+                        hc_pattern_step<uint16_t, const lds_u16 *>(src, lk, pos, m, pattern, 0u, limit, best_len, best_off);
+                    const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
+                    if (found) res[pos] = (uint32_t)best_len | (best_off << 16);
+                    pos += found ? (uint32_t)best_len : 1u;      // :1013-1016, :382
+                    in_chain = false;
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ K3: greedy parse + emit
@@ -412,14 +567,34 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * sizeof(T)));
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+        static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
+        const bool seg_search = sizeof(T) == 2 && !optimal && !legacy_search;
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, b0, nb);
-        static const uint32_t k2_threads = [] { const char *e = getenv("ZLZ4_HC_SEARCH_THREADS"); const uint32_t v = e ? (uint32_t)atoi(e) : 64u;
-                                                return (v == 64u || v == 128u || v == 256u) ? v : 64u; }();
-        // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a workgroup
-        //  finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
-        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + k2_threads - 1u) / k2_threads, nb), dim3(k2_threads), 0, stream, d_in,
-                           d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0);
+                           d_in_len, d_link, stride, b0, nb, seg_search ? reinterpret_cast<uint32_t *>(d_res) : nullptr);
+        if constexpr (sizeof(T) == 2) {
+            if (!optimal && !legacy_search) {
+                // parse-aware search: one lane per 64-position segment, links in LDS
+                const uint32_t seg_len = 32;                                     // start points of the speculative walks
+                const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
+                uint32_t threads = (nseg_max / 2u + 63u) & ~63u;                 // ~2 start points per lane
+                if (threads > 1024u) threads = 1024u;
+                if (threads < 64u) threads = 64u;
+                const uint32_t lk_bytes = (np_max * 2u + 15u) & ~15u;
+                const uint32_t lds = lk_bytes + ((np_max + 31u) / 32u + 1u) * 4u;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_seg_search),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k_hc_seg_search, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
+                                   reinterpret_cast<const uint16_t *>(d_link), stride, reinterpret_cast<uint32_t *>(d_res), b0, nb,
+                                   max_attempts, max_in_len, lk_bytes, seg_len);
+            }
+        }
+        if (sizeof(T) != 2 || optimal || legacy_search) {
+            // every position (the price-based parse of levels 10-12 looks results up everywhere; blocks > 64 KiB)
+            // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
+            //  workgroup finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
+            hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 63u) / 64u, nb), dim3(64), 0, stream, d_in,
+                               d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0);
+        }
         if (optimal) {
             const int rc = zlz4_launch_hc_opt_parse(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
                                                     d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len);
