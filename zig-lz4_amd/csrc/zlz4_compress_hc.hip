@@ -29,9 +29,9 @@
 #include "zlz4_device.hpp"
 
 #ifdef ZLZ4_STAMPS
-__device__ unsigned long long g_zlz4_hstamps[4];
+__device__ unsigned long long g_zlz4_hstamps[8];
 extern "C" int zlz4_debug_read_hstamps(unsigned long long *out4) {
-    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_zlz4_hstamps), 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -7;
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_zlz4_hstamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -7;
 }
 #endif
 
@@ -85,12 +85,15 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
         for (uint32_t k = lane; k < kHcTableSize * sizeof(T) / 16u; k += 64u) t4[k] = z;   // Context.init :405-419
     }
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
+    uint32_t seq_next = lane < np ? ld32(src + lane) : 0u;
     for (uint32_t base = 0; base < np; base += 64u) {
         const uint32_t q = base + lane;
         const bool active = q < np;
+        const uint32_t seq = seq_next;
+        if (q + 64u < np) seq_next = ld32(src + q + 64u);   // next step's bytes are in flight during this step
         uint32_t h = 0, old = 0, rb = 0;
         if (active) {
-            h = hash_hc(ld32(src + q));                 // insertHC :499
+            h = hash_hc(seq);                           // insertHC :499
             old = table[h];                             // :500
             table[h] = (T)q;                            // :505
         }
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
+template <int kCands>   // candidates of a chain examined per loop trip (1, 2 or 4)
 __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restrict__ d_in,
                                                          const uint64_t *__restrict__ d_in_off,
                                                          const uint32_t *__restrict__ d_in_len,
@@ -340,10 +344,22 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 
-    bool have = false, exhausted = false, in_chain = false;
-    uint32_t pos = 0, m = 0, off = 0, avail = 0, best_off = 0, pattern = 0;
+    bool have = false, exhausted = false, in_chain = false, in_ext = false, fresh = false;
+    u32x4 p16 = {0, 0, 0, 0};                                    // the 16 bytes at pos
+    u32x4 aw = p16;                                              // the 16 bytes at pos + aw_off (the compare window)
+    uint32_t aw_off = 0;
+    uint32_t pos = 0, m = 0, off = 0, avail = 0, best_off = 0;
     int32_t nb = 0, best_len = (int32_t)kMinMatch - 1;
+#ifdef ZLZ4_STAMPS
+    unsigned long long st_trips = 0, st_chain = 0, st_fetch = 0, st_walks = 0, t_assign = 0, t_fetch = 0, t_chain = 0;
+#define HSTAMP(acc, t0) acc += __builtin_amdgcn_s_memtime() - t0
+#define HNOW() __builtin_amdgcn_s_memtime()
+#else
+#define HSTAMP(acc, t0)
+#define HNOW() 0
+#endif
     for (;;) {
+        [[maybe_unused]] unsigned long long t0 = HNOW();
         // ---- start points for the lanes that have none
         const uint64_t want = ballot(!have && !exhausted);
         if (want) {
@@ -357,23 +373,34 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
             }
         }
         if (!ballot(have)) break;
-        // ---- next position of the walk: stop at a marked one; positions whose hash was never seen before (no candidate,
-        //      :566-568) cost two LDS operations each, a few of them per trip
+        HSTAMP(t_assign, t0);
+#ifdef ZLZ4_STAMPS
+        st_trips += 1; st_walks += __popcll(want); st_fetch += __popcll(ballot(have && !in_chain));
+        t0 = HNOW();
+#endif
+        // ---- next position of the walk.  Positions whose hash was never seen before have no candidate (:566-568): the
+        //      parse steps over them one by one (:1013-1016) and they cost one LDS read each, four per round trip.  Only
+        //      positions WITH candidates are marked and tested: walks inside the same run of candidate-less positions all
+        //      reach the position that ends the run, and merge there.
         if (have && !in_chain) {
-            for (int it = 0; it < 3; ++it) {
+            for (int it = 0; it < 2; ++it) {
                 if (pos >= np) { have = false; break; }
+                const uint32_t l0 = lk[pos], l1 = lk[pos + 1u], l2 = lk[pos + 2u], l3 = lk[pos + 3u];   // (LDS is padded)
+                const uint32_t k = l0 != pos ? 0u : l1 != pos + 1u ? 1u : l2 != pos + 2u ? 2u : l3 != pos + 3u ? 3u : 4u;
+                pos += k;
+                if (pos >= np) { have = false; break; }          // (also ends a run that ran into the garbage past np)
+                if (k == 4u) continue;
+                const uint32_t l = k == 0u ? l0 : k == 1u ? l1 : k == 2u ? l2 : l3;
                 const uint32_t bit = 1u << (pos & 31u);
                 const uint32_t old = __hip_atomic_fetch_or(bm + (pos >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t l = lk[pos];
-                if (old & bit) { have = false; break; }
-                m = pos - l;                                     // :563 hashTable[hashPtr(ip)] (0 = none)
-                if (m == 0) { pos += 1; continue; }              // no match: res[pos] stays 0, :1013-1016
+                if (old & bit) { have = false; break; }          // somebody else's walk continues from here
+                m = pos - l;                                     // :563 hashTable[hashPtr(ip)], != 0 here
                 best_len = (int32_t)kMinMatch - 1;               // :560
                 best_off = 0;
                 nb = max_attempts;
                 if (pos + 16u > n) {
                     // the last <= 4 searchable positions of a block: no room for 16-byte compares
-                    pattern = ld32(src + pos);
+                    const uint32_t pattern = ld32(src + pos);
                     while (m > 0 && nb > 0) {                    // :571 (m <= pos and pos - m <= 65535 hold for u16 links)
                         nb -= 1;                                 // :577
                         const uint32_t delta = lk[m];
@@ -398,45 +425,116 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 avail = limit - pos;                             // lz4Count stops at iHighLimit
                 off = 0;
                 in_chain = true;
+                in_ext = false;
+                fresh = true;
                 break;
             }
         }
+        HSTAMP(t_fetch, t0);
+#ifdef ZLZ4_STAMPS
+        st_chain += __popcll(ballot(have && in_chain));
+        t0 = HNOW();
+#endif
         // ---- one round trip of the chain walk :571-622
         if (have && in_chain) {
-            const uint32_t delta = lk[m];                        // :619 chainTable[matchIndex]
-            const u32x4 a16 = ld128(src + pos + off);
-            const u32x4 b16 = ld128(src + m + off);              // m < pos, so m + off + 16 <= n too
-            if (off == 0) pattern = a16.x;
-            const uint32_t d = first_diff16_sel(a16, b16);
-            uint32_t total = off + d;
-            bool more = d == 16u && total < avail;
-            if (more && pos + total + 16u > n) {                 // no room for another 16-byte compare: finish by bytes
-                total += lz4_count(src, pos + total, m + total, limit);
-                more = false;
-            }
-            if (more) {
-                off = total;                                     // same candidate, next 16 bytes
-            } else {
+            // a candidate is done: :577, :586-:621.  `total` = its match length (bytes equal to the ones at pos, not yet
+            // clamped), or 0 for a candidate that is known not to beat best_len (the reference counts those in full,
+            // :588, but only `mlt > longest` is ever used, :607)
+            bool changed = false;
+            auto complete = [&](uint32_t c, uint32_t delta, uint32_t total) -> bool {
                 nb -= 1;                                         // :577
                 const int32_t mlt = total >= kMinMatch ? (int32_t)(total < avail ? total : avail) : 0;   // :586, :588
                 const bool better = mlt > best_len;              // :607
+                changed = changed | better;
                 best_len = better ? mlt : best_len;
-                best_off = better ? pos - m : best_off;
-                const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > m);   // :613, :620
-                m = stop ? m : m - delta;                        // :621
-                off = 0;
-                const bool go = (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0));
-                if (!go) {
-                    if (pattern_analysis)
-                        hc_pattern_step<uint16_t, const lds_u16 *>(src, lk, pos, m, pattern, 0u, limit, best_len, best_off);
-                    const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
-                    if (found) res[pos] = (uint32_t)best_len | (best_off << 16);
-                    pos += found ? (uint32_t)best_len : 1u;      // :1013-1016, :382
-                    in_chain = false;
+                best_off = better ? pos - c : best_off;
+                const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > c);   // :613, :620
+                m = stop ? c : c - delta;                        // :621
+                return (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0));
+            };
+            bool done = false;                                   // the search at pos is over
+            if (!in_ext) {
+                // up to kCands candidates per trip: the links are chased in LDS first (the walk itself does not depend on
+                // the compares), then the 16-byte loads fly together.  A candidate can only matter if it matches MORE
+                // than best_len bytes, so what is compared first is the 16-byte window that ends at byte best_len
+                // (bytes 0..15 while best_len < 16): a mismatch there settles it in one load, whatever the candidate's
+                // real length -- at level 9 a frequent 4-gram has 256 candidates that match 20-40 bytes each.
+                const uint32_t w = best_len >= 16 ? (uint32_t)best_len - 15u : 0u;
+                const uint32_t c0 = m, l0 = lk[c0];
+                uint32_t c1 = 0, l1 = 0, c2 = 0, l2 = 0, c3 = 0, l3 = 0;
+                u32x4 b1 = {0, 0, 0, 0}, b2 = b1, b3 = b1;
+                if constexpr (kCands >= 2) {
+                    const bool k1 = !(l0 == 0 || l0 > c0) && c0 - l0 > 0;
+                    c1 = k1 ? c0 - l0 : 0; l1 = lk[c1];
+                    if constexpr (kCands >= 4) {
+                        const bool k2 = k1 && !(l1 == 0 || l1 > c1) && c1 - l1 > 0;
+                        c2 = k2 ? c1 - l1 : 0; l2 = lk[c2];
+                        const bool k3 = k2 && !(l2 == 0 || l2 > c2) && c2 - l2 > 0;
+                        c3 = k3 ? c2 - l2 : 0; l3 = lk[c3];
+                    }
                 }
+                if (fresh) { p16 = ld128(src + pos); aw_off = 0; fresh = false; }
+                if (aw_off != w) { aw = ld128(src + pos + w); aw_off = w; }      // pos + w + 16 = pos + best_len + 1 <= n - 4
+                const u32x4 awin = w == 0u ? p16 : aw;           // (a select after the loads: no wait on p16 alone)
+                const u32x4 b0 = ld128(src + c0 + w);
+                if constexpr (kCands >= 2) b1 = ld128(src + c1 + w);
+                if constexpr (kCands >= 4) { b2 = ld128(src + c2 + w); b3 = ld128(src + c3 + w); }
+                // (a candidate slot that the walk does not reach holds position 0: a harmless load, never looked at;
+                //  after a candidate that raised best_len the rest of the trip is dropped: their window is stale)
+                #define ZLZ4_HC_CAND(C, L, B)                                                                   \
+                    if (!done && !in_ext && !changed) {                                                         \
+                        const uint32_t fd = first_diff16_sel(awin, B);                                          \
+                        if (w != 0) {                                                                           \
+                            if (fd == 16u) { m = (C); off = 0; in_ext = true; }          /* count it from byte 0 */ \
+                            else if (!complete((C), (L), 0u)) done = true;                                      \
+                        } else {                                                                                \
+                            uint32_t total = fd;                                                                \
+                            bool more = total == 16u && total < avail;                                          \
+                            if (more && pos + 32u > n) { total += lz4_count(src, pos + 16u, (C) + 16u, limit); more = false; } \
+                            if (more) { m = (C); off = 16u; in_ext = true; }                                    \
+                            else if (!complete((C), (L), total)) done = true;                                   \
+                        }                                                                                       \
+                    }
+                ZLZ4_HC_CAND(c0, l0, b0)
+                if constexpr (kCands >= 2) { ZLZ4_HC_CAND(c1, l1, b1) }
+                if constexpr (kCands >= 4) { ZLZ4_HC_CAND(c2, l2, b2) ZLZ4_HC_CAND(c3, l3, b3) }
+                #undef ZLZ4_HC_CAND
+            } else {
+                // the candidate at m matched `off` bytes so far: the next 16
+                const uint32_t delta = lk[m];                    // :619 chainTable[matchIndex]
+                const u32x4 a16 = ld128(src + pos + off);
+                const u32x4 b16 = ld128(src + m + off);          // m < pos, so m + off + 16 <= n too
+                uint32_t total = off + first_diff16_sel(a16, b16);
+                bool more = total == off + 16u && total < avail;
+                if (more && pos + total + 16u > n) {             // no room for another 16-byte compare: finish by bytes
+                    total += lz4_count(src, pos + total, m + total, limit);
+                    more = false;
+                }
+                if (more) off = total;
+                else { in_ext = false; done = !complete(m, delta, total); }
+            }
+            if (done) {
+                if (pattern_analysis)
+                    hc_pattern_step<uint16_t, const lds_u16 *>(src, lk, pos, m, p16.x, 0u, limit, best_len, best_off);
+                const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
+#ifndef ZLZ4_EXPERIMENT_NOSTORE
+                if (found) res[pos] = (uint32_t)best_len | (best_off << 16);
+#endif
+                pos += found ? (uint32_t)best_len : 1u;          // :1013-1016, :382
+                in_chain = false;
             }
         }
+        HSTAMP(t_chain, t0);
     }
+#ifdef ZLZ4_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_zlz4_hstamps[0], st_chain); atomicAdd(&g_zlz4_hstamps[1], st_trips); atomicAdd(&g_zlz4_hstamps[2], st_fetch);
+        atomicAdd(&g_zlz4_hstamps[3], st_walks); atomicAdd(&g_zlz4_hstamps[4], t_assign); atomicAdd(&g_zlz4_hstamps[5], t_fetch);
+        atomicAdd(&g_zlz4_hstamps[6], t_chain);
+    }
+#endif
+#undef HSTAMP
+#undef HNOW
 }
 
 // ------------------------------------------------------------------ K3: greedy parse + emit
@@ -480,11 +578,22 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
         // 64-position window of search results held in registers
         uint32_t wbase = 0;
         R w = (lane <= mflimit) ? res[lane] : (R)0;
+        // lanes of the window whose position holds a match; the loop steps over the others one by one (:1013-1016), i.e.
+        // it goes to the first such lane at or after ip
+        auto is_match = [](R r) {
+            if (sizeof(R) == 4) return ((uint32_t)r & 0xFFFFu) >= kMinMatch && ((uint32_t)r >> 16) != 0;
+            return (uint32_t)r >= kMinMatch && (uint32_t)((uint64_t)r >> 32) != 0;
+        };
+        uint64_t wmatch = ballot(is_match(w));
         while (ip <= mflimit) {                                  // :1009
             if (ip - wbase >= 64u) {
                 wbase = ip;
                 w = (ip + lane <= mflimit) ? res[ip + lane] : (R)0;
+                wmatch = ballot(is_match(w));
             }
+            const uint64_t ahead = wmatch >> (ip - wbase);
+            if (ahead == 0) { ip = wbase + 64u; continue; }      // no match in the rest of the window
+            ip += first_lane(ahead);
             uint32_t len, off;
             if (sizeof(R) == 4) {
                 const uint32_t r = rdlane((uint32_t)w, ip - wbase);
@@ -493,7 +602,6 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
                 len = rdlane((uint32_t)w, ip - wbase);
                 off = rdlane((uint32_t)((uint64_t)w >> 32), ip - wbase);
             }
-            if (len < kMinMatch || off == 0) { ip += 1; continue; }   // :1013-1016
             // encodeSequence (:308-386) with limitedOutput
             const uint32_t lit = ip - anchor;                    // :317
             if ((uint64_t)op + lit / 255u + lit + (2u + 1u + kLastLiterals) > oend) { failed = true; break; }   // :320-325
@@ -574,16 +682,18 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         if constexpr (sizeof(T) == 2) {
             if (!optimal && !legacy_search) {
                 // parse-aware search: one lane per 64-position segment, links in LDS
-                const uint32_t seg_len = 32;                                     // start points of the speculative walks
+                static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
+                static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
                 const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
-                uint32_t threads = (nseg_max / 2u + 63u) & ~63u;                 // ~2 start points per lane
+                uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;            // ~2 start points per lane
                 if (threads > 1024u) threads = 1024u;
                 if (threads < 64u) threads = 64u;
-                const uint32_t lk_bytes = (np_max * 2u + 15u) & ~15u;
+                const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;    // + padding: the walk reads 3 links ahead
                 const uint32_t lds = lk_bytes + ((np_max + 31u) / 32u + 1u) * 4u;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_seg_search),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(k_hc_seg_search, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
+                static const int cands = [] { const char *e = getenv("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
+                auto kern = cands == 4 ? &k_hc_seg_search<4> : cands == 2 ? &k_hc_seg_search<2> : &k_hc_seg_search<1>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
                                    reinterpret_cast<const uint16_t *>(d_link), stride, reinterpret_cast<uint32_t *>(d_res), b0, nb,
                                    max_attempts, max_in_len, lk_bytes, seg_len);
             }
