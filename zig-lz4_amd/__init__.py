@@ -214,6 +214,16 @@ class lz4f:
         s, n = _in(src)
         return _check(lib().zlz4f_header_size(C.addressof(s), n))
 
+    # device-resident variants (torch CUDA uint8 tensors in, frame / content size out)
+    @staticmethod
+    def compressFrameDevice(d_src, d_dst, prefs=None):
+        return _check(lib().zlz4f_compress_frame_device(_stream(), _ptr(d_src), d_src.numel(), _ptr(d_dst), d_dst.numel(),
+                                                        C.byref(prefs) if prefs is not None else None))
+
+    @staticmethod
+    def decompressFrameDevice(d_frame, frame_len, d_dst):
+        return _check(lib().zlz4f_decompress_frame_device(_stream(), _ptr(d_frame), frame_len, _ptr(d_dst), d_dst.numel()))
+
 
 # ----------------------------------------------------------------------------- batch (device pointers)
 def _ptr(t):
