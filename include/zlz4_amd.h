@@ -83,7 +83,16 @@ int64_t zlz4_compress_fast(const uint8_t *src, size_t src_len, uint8_t *dst, siz
                            uint32_t acceleration);
 
 /* replaces lz4hc.compressHC, src/lz4hc.zig:1440-1453.  Levels <2 -> 9, >12 -> 12 (:1445).
- * All strategies of the level table (:72-86) run on the device: 2 lz4mid, 3..9 lz4hc, 10..12 lz4opt. */
+ * All strategies of the level table (:72-86) run on the device: 2 lz4mid, 3..9 lz4hc, 10..12 lz4opt.
+ *
+ * HAZARD, levels 10..12: the output is the reference's output byte for byte, and the reference's lz4opt has a defect
+ * (its "good enough -> encode now" branch, src/lz4hc.zig:1207-1256, reads arrival records as forward steps): the
+ * stream it emits does NOT always decode back to the input.  Level 10 loses ordinary text blocks (every 64 KiB block
+ * of the benchmark's text), levels 11 and 12 lose some inputs; a few inputs return OutputTooSmall where the reference
+ * itself underflows.  Bit-parity with the reference is the contract here, so nothing is "fixed" silently: callers that
+ * need their data back should use levels 2..9, or verify by decoding (zlz4_decompress_safe) before they drop the
+ * source.  The same applies to zlz4f_compress_frame(_device) with compression_level >= 10 -- add a content checksum
+ * there and the decoder will at least report the damage. */
 int64_t zlz4_compress_hc(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                          int32_t compression_level);
 
@@ -117,6 +126,12 @@ int64_t zlz4_compress_dest_size(const uint8_t *src, uint8_t *dst, size_t dst_cap
  *    the single-buffer call would have returned for that block.  All arrays
  *    live in device memory.  Kernels are enqueued on `stream` (hipStream_t)
  *    and the call returns without synchronising.  Return: 0 or ZLZ4_ERR_*.
+ *
+ *    PRECONDITION of the compress calls: d_in_len[i] <= max_in_len for every
+ *    block.  max_in_len selects the table width (16-bit positions up to
+ *    64 KiB blocks) and sizes the HC workspace; a block that is longer gets
+ *    d_result[i] = ZLZ4_ERR_INVALID_STATE and is not compressed (nothing is
+ *    written outside its own output slot, the other blocks are unaffected).
  * ====================================================================== */
 int32_t zlz4_batch_compress_fast(void *stream,
                                  const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
@@ -169,6 +184,26 @@ int64_t zlz4f_compress_frame_device(void *stream, const uint8_t *d_src, size_t s
                                     uint8_t *d_dst, size_t dst_cap, const zlz4f_prefs *prefs);
 int64_t zlz4f_decompress_frame_device(void *stream, const uint8_t *d_src, size_t src_len,
                                       uint8_t *d_dst, size_t dst_cap);
+
+/* One frame over several GPUs (BASELINE configs[4]).  compressFrame's block loop (src/lz4f.zig:379-430) carries no
+ * state from block to block, so rank r of G compresses its contiguous range of blocks and the frame is the plain
+ * concatenation of the ranks' segments in rank order:
+ *     segment = [frame header, if ZLZ4F_SEG_FIRST] [block header, data, block checksum]* [end mark, if ZLZ4F_SEG_LAST]
+ * d_src is the rank's byte range of the input; every range but the last must be a multiple of the block size.  The
+ * only cross-rank step is the prefix sum of the returned segment sizes (where each segment goes).  A content checksum
+ * is one serial XXH32 chain over the whole input (:384-386) and is refused here (ZLZ4_ERR_UNSUPPORTED) unless the
+ * segment is the whole frame.  With both flags the call is zlz4f_compress_frame_device. */
+#define ZLZ4F_SEG_FIRST 1u
+#define ZLZ4F_SEG_LAST  2u
+int64_t zlz4f_compress_frame_segment_device(void *stream, const uint8_t *d_src, size_t src_len,
+                                            uint8_t *d_dst, size_t dst_cap, const zlz4f_prefs *prefs,
+                                            uint32_t segment_flags);
+/* The inverse for one rank: decodes the blocks of a segment (src/lz4f.zig:563-621).  A segment without
+ * ZLZ4F_SEG_FIRST has no frame header, so `prefs` must carry the frame's block_checksum flag and block_size_id
+ * (what rank 0 read from the header); without ZLZ4F_SEG_LAST no end mark is expected. */
+int64_t zlz4f_decompress_frame_segment_device(void *stream, const uint8_t *d_src, size_t src_len,
+                                              uint8_t *d_dst, size_t dst_cap, const zlz4f_prefs *prefs,
+                                              uint32_t segment_flags);
 
 /* ======================================================================
  * 4. Introspection

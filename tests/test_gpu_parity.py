@@ -217,3 +217,32 @@ def test_decoder_batch_path_malformed_and_capacity_stress(zl, oracle, gpu):
     assert sum(isinstance(w, int) for w in want) > 100 and sum(not isinstance(w, int) for w in want) > 50
     got = gh.decompress(zl, comp, caps, gpu)
     _cmp(names, got, want)
+
+
+def test_batch_max_in_len_understated(zl, oracle, gpu):
+    """A block longer than the call's max_in_len is refused (InvalidState) and its neighbours are unaffected."""
+    import torch
+    items = [bytes(dg.text_bytes(3000, 1)), bytes(dg.text_bytes(70000, 2)), bytes(dg.text_bytes(5000, 3)), bytes(dg.text_bytes(66000, 4))]
+    for kind, level, lie in (("fast", 0, 8192), ("hc", 9, 8192), ("hc", 12, 8192), ("hc", 9, 65536), ("fast", 0, 65536)):
+        buf, offs, lens = gh._pack(items)
+        caps = np.array([zl.compressBound(len(b)) for b in items], dtype=np.int64)
+        out_offs = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16 + 64)[:-1]]).astype(np.int64)
+        d_in = torch.from_numpy(buf).to(gpu)
+        d_out = torch.zeros(int(out_offs[-1] + caps[-1] + 80), dtype=torch.uint8, device=gpu)
+        res = torch.full((len(items),), -999, dtype=torch.int64, device=gpu)
+        a = (torch.from_numpy(offs).to(gpu), torch.from_numpy(lens.astype(np.uint32).view(np.int32)).to(gpu), d_out,
+             torch.from_numpy(out_offs).to(gpu), torch.from_numpy(caps.astype(np.uint32).view(np.int32)).to(gpu), res)
+        if kind == "fast":
+            zl.batch_compress_fast(d_in, *a, lie, 1)
+        else:
+            ws = torch.empty(max(16, zl.batch_compress_hc_workspace(len(items), lie)), dtype=torch.uint8, device=gpu)
+            zl.batch_compress_hc(d_in, *a, lie, level, ws)
+        torch.cuda.synchronize()
+        r = res.cpu().numpy()
+        o = d_out.cpu().numpy()
+        for i, b in enumerate(items):
+            if len(b) > lie:
+                assert r[i] == -5, (kind, level, lie, i, r[i])
+            else:
+                want = oracle.compress_default(b) if kind == "fast" else oracle.compress_hc(b, level)
+                assert r[i] == len(want) and bytes(o[out_offs[i]: out_offs[i] + r[i]]) == want, (kind, level, lie, i)

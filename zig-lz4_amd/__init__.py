@@ -73,6 +73,8 @@ SYMBOLS = {
     "zlz4f_header_size": (_I64, [_VP, _SZ]),
     "zlz4f_compress_frame_device": (_I64, [_VP, _VP, _SZ, _VP, _SZ, _PP]),
     "zlz4f_decompress_frame_device": (_I64, [_VP, _VP, _SZ, _VP, _SZ]),
+    "zlz4f_compress_frame_segment_device": (_I64, [_VP, _VP, _SZ, _VP, _SZ, _PP, _U32]),
+    "zlz4f_decompress_frame_segment_device": (_I64, [_VP, _VP, _SZ, _VP, _SZ, _PP, _U32]),
     "zlz4_device_check": (_I32, []),
     "zlz4_version_string": (C.c_char_p, []),
     "zlz4_error_name": (C.c_char_p, [_I64]),
@@ -223,6 +225,20 @@ class lz4f:
     @staticmethod
     def decompressFrameDevice(d_frame, frame_len, d_dst):
         return _check(lib().zlz4f_decompress_frame_device(_stream(), _ptr(d_frame), frame_len, _ptr(d_dst), d_dst.numel()))
+
+    SEG_FIRST, SEG_LAST = 1, 2
+
+    @staticmethod
+    def compressFrameSegmentDevice(d_src, d_dst, prefs, seg_flags):
+        """One rank's block segment of a frame split over several GPUs (include/zlz4_amd.h)."""
+        return _check(lib().zlz4f_compress_frame_segment_device(_stream(), _ptr(d_src), d_src.numel(), _ptr(d_dst),
+                                                                d_dst.numel(), C.byref(prefs) if prefs is not None else None,
+                                                                seg_flags))
+
+    @staticmethod
+    def decompressFrameSegmentDevice(d_seg, seg_len, d_dst, prefs, seg_flags):
+        return _check(lib().zlz4f_decompress_frame_segment_device(_stream(), _ptr(d_seg), seg_len, _ptr(d_dst), d_dst.numel(),
+                                                                  C.byref(prefs) if prefs is not None else None, seg_flags))
 
 
 # ----------------------------------------------------------------------------- batch (device pointers)

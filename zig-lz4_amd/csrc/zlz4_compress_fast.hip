@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
     const uint64_t *__restrict__ d_out_off, const uint32_t *__restrict__ d_out_cap,
-    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration, uint32_t tune_restart) {
+    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration, uint32_t tune_restart, uint32_t max_in_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_wg = threadIdx.x >> 6;
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
     int64_t res;
     if (src_size > kMaxInput) {                                         // :296
         res = kErrInputTooLarge;
+    } else if (src_size > max_in_len) {                                 // the table width was chosen from max_in_len
+        res = kErrInvalidState;
     } else if (src_size == 0) {                                         // :299
         res = 0;
     } else if (src_size < kMfLimit + 1u) {                              // :302-304
@@ -654,12 +656,12 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
         const uint32_t wpw = (tune_wpw == 2 || tune_wpw == 4) ? tune_wpw : 1;
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint16_t) + lds_pad, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration, restart);
+                           d_out_cap, d_result, nblocks, acceleration, restart, max_in_len);
     } else {
         const uint32_t wpw = (tune_wpw == 2) ? 2 : 1;   // 16 KiB of LDS per wavefront -> 10 wavefronts per CU
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint32_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint32_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration, restart);
+                           d_out_cap, d_result, nblocks, acceleration, restart, max_in_len);
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }

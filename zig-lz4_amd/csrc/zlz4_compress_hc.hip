@@ -67,13 +67,14 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
                                                         const uint64_t *__restrict__ d_in_off,
                                                         const uint32_t *__restrict__ d_in_len, T *__restrict__ d_link,
                                                         uint64_t link_stride, uint32_t blk0, uint32_t nblocks,
-                                                        uint32_t *__restrict__ d_zero_res) {
+                                                        uint32_t *__restrict__ d_zero_res, uint32_t max_in_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const uint8_t *src = d_in + d_in_off[blk0 + b];
     const uint32_t n = rfl(d_in_len[blk0 + b]);
+    if (n > max_in_len) return;                         // the workspace stride comes from max_in_len; K3 reports it
     const uint32_t np = n_positions(n);
     T *link = d_link + (uint64_t)b * link_stride;
     uint32_t *zero_res = d_zero_res ? d_zero_res + (uint64_t)b * link_stride : nullptr;   // K2s stores matches only
@@ -200,10 +201,12 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
                                                     const uint32_t *__restrict__ d_in_len,
                                                     const T *__restrict__ d_link, uint64_t link_stride,
                                                     R *__restrict__ d_res, uint32_t blk0, uint32_t nblocks,
-                                                    int32_t max_attempts, int32_t force_pattern_analysis) {
+                                                    int32_t max_attempts, int32_t force_pattern_analysis,
+                                                    uint32_t max_in_len) {
     const uint32_t b = blockIdx.y;
     if (b >= nblocks) return;
     const uint32_t n = d_in_len[blk0 + b];
+    if (n > max_in_len) return;
     const uint32_t np = n_positions(n);
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= np) return;
@@ -546,7 +549,8 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
                                                         const uint64_t *__restrict__ d_out_off,
                                                         const uint32_t *__restrict__ d_out_cap,
                                                         int64_t *__restrict__ d_result, const R *__restrict__ d_res,
-                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks) {
+                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks,
+                                                        uint32_t max_in_len) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (b >= nblocks) return;
@@ -560,6 +564,8 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
     int64_t out;
     if (n > kMaxInput) {                                         // :1442
         out = kErrInputTooLarge;
+    } else if (n > max_in_len) {                                 // K1/K2 skipped it: nothing of it is in the workspace
+        out = kErrInvalidState;
     } else if (n == 0) {                                         // :1443
         out = 0;
     } else if (oend == 0) {                                      // :1461
@@ -647,7 +653,7 @@ extern "C" int zlz4_launch_hc_mid(hipStream_t, const uint8_t *, const uint64_t *
                                   const uint32_t *, int64_t *, uint32_t, void *, uint32_t);
 extern "C" int zlz4_launch_hc_opt_parse(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
                                         const uint64_t *, const uint32_t *, int64_t *, const void *, uint64_t, int, void *,
-                                        uint32_t, uint32_t, uint32_t);
+                                        uint32_t, uint32_t, uint32_t, uint32_t);
 extern "C" size_t zlz4_hc_mid_workspace_bytes(uint32_t chunk_blocks);
 extern "C" size_t zlz4_hc_opt_workspace_bytes(uint32_t chunk_blocks);
 
@@ -678,7 +684,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
         const bool seg_search = sizeof(T) == 2 && !optimal && !legacy_search;
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, b0, nb, seg_search ? reinterpret_cast<uint32_t *>(d_res) : nullptr);
+                           d_in_len, d_link, stride, b0, nb, seg_search ? reinterpret_cast<uint32_t *>(d_res) : nullptr, max_in_len);
         if constexpr (sizeof(T) == 2) {
             if (!optimal && !legacy_search) {
                 // parse-aware search: one lane per 64-position segment, links in LDS
@@ -703,15 +709,15 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
             // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
             //  workgroup finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
             hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 63u) / 64u, nb), dim3(64), 0, stream, d_in,
-                               d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0);
+                               d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0, max_in_len);
         }
         if (optimal) {
             const int rc = zlz4_launch_hc_opt_parse(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
-                                                    d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len);
+                                                    d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len, max_in_len);
             if (rc != 0) return rc;
         } else {
             hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
-                               d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb);
+                               d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb, max_in_len);
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;

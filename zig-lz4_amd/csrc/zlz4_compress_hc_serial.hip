@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void k_hc_opt_parse(const uint8_t *__restrict__
                                                       const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result,
                                                       const R *__restrict__ d_res, uint64_t res_stride,
                                                       OptEntry *__restrict__ d_opt, uint32_t blk0, uint32_t nblocks,
-                                                      uint32_t sufficient_len_in) {
+                                                      uint32_t sufficient_len_in, uint32_t max_in_len) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     const uint32_t blk = blk0 + b;
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64) void k_hc_opt_parse(const uint8_t *__restrict__
     const uint32_t n = d_in_len[blk], oend = d_out_cap[blk];
     int64_t out;
     if (n > kMaxInput) out = kErrInputTooLarge;
+    else if (n > max_in_len) out = kErrInvalidState;                              // not in the K1/K2 workspace
     else if (n == 0) out = 0;
     else if (oend == 0) out = kErrOutputTooSmall;
     else if (n < kMfLimit + 1u) out = tiny_block_lane(src, dst, oend, n);         // :1092-1094
@@ -374,14 +375,15 @@ extern "C" int zlz4_launch_hc_mid(hipStream_t stream, const uint8_t *d_in, const
 extern "C" int zlz4_launch_hc_opt_parse(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
                                         const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                                         const uint32_t *d_out_cap, int64_t *d_result, const void *d_res, uint64_t res_stride,
-                                        int wide, void *d_opt, uint32_t b0, uint32_t nb, uint32_t sufficient_len) {
+                                        int wide, void *d_opt, uint32_t b0, uint32_t nb, uint32_t sufficient_len,
+                                        uint32_t max_in_len) {
     if (wide)
         hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint64_t>, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len,
                            d_out, d_out_off, d_out_cap, d_result, static_cast<const uint64_t *>(d_res), res_stride,
-                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len);
+                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len, max_in_len);
     else
         hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint32_t>, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len,
                            d_out, d_out_off, d_out_cap, d_result, static_cast<const uint32_t *>(d_res), res_stride,
-                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len);
+                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len, max_in_len);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }

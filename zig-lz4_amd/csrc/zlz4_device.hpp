@@ -22,6 +22,7 @@ constexpr uint32_t kHashMul = 2654435761u;   // src/lz4.zig:44
 constexpr int64_t kErrOutputTooSmall = -1;   // lz4.Error order, src/lz4.zig:48-55
 constexpr int64_t kErrInputTooLarge = -2;
 constexpr int64_t kErrCorrupted = -3;
+constexpr int64_t kErrInvalidState = -5;   // also: a batch block longer than the call's max_in_len (include/zlz4_amd.h)
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }

@@ -118,11 +118,10 @@ HeaderBytes encode_header(const zlz4f_prefs &p) {
 struct ParsedHeader { int64_t size; uint8_t flg; size_t block_size; };
 
 // parseFrameHeader, src/lz4f.zig:483-538 (decodeFLG :187-221, decodeBD :235-249); `have` = bytes available
-ParsedHeader parse_header(const uint8_t *src, size_t have) {
+__host__ __device__ inline ParsedHeader parse_header(const uint8_t *src, size_t have) {
     ParsedHeader r = {0, 0, 0};
     if (have < 7) { r.size = ZLZ4F_ERR_FRAME_HEADER_INCOMPLETE; return r; }
-    uint32_t magic;
-    std::memcpy(&magic, src, 4);
+    const uint32_t magic = zx_rd32(src);
     if (magic != ZLZ4F_MAGICNUMBER) { r.size = ZLZ4F_ERR_FRAME_TYPE_UNKNOWN; return r; }
     size_t pos = 4;
     const uint8_t flg = src[pos];
@@ -152,20 +151,33 @@ ParsedHeader parse_header(const uint8_t *src, size_t have) {
 // ------------------------------------------------------------------ device buffers
 // Scratch memory of the frame calls (block slots, descriptors, plans).  hipMalloc / hipFree of a multi-GiB slot arena
 // cost milliseconds and hipFree synchronises the device, so freed buffers are parked in a small per-process cache
-// and handed out again (every frame call synchronises its stream before it returns, so a parked buffer is idle).
+// and handed out again.  A buffer may only be parked once the work that uses it has finished: every DevBuf belongs to
+// a FrameCall, and the first DevBuf that dies while the call's stream may still be busy (an early error return after
+// kernels were enqueued) synchronises the stream first.  The cache is bounded by count AND by bytes;
 // zlz4_release_device_cache() gives the memory back.
 namespace {
 struct ParkedBuf { void *p; size_t n; int dev; };
 std::mutex g_park_mutex;
 std::vector<ParkedBuf> g_parked;
+size_t g_parked_bytes = 0;
 constexpr size_t kMaxParked = 12;
+constexpr size_t kMaxParkedBytes = 8ull << 30;   // ~3 % of the HBM: one configs[4] slot arena (4 GiB) and its tables
 }  // namespace
+
+struct FrameCall {
+    hipStream_t st;
+    bool idle = true;                 // false between the first launch and the stream synchronisation that follows it
+    explicit FrameCall(hipStream_t s) : st(s) {}
+    void launched() { idle = false; }
+    bool sync() { idle = true; return hipStreamSynchronize(st) == hipSuccess; }
+};
 
 struct DevBuf {
     void *p = nullptr;
     size_t n = 0;
     int dev = 0;
-    explicit DevBuf(size_t want) {
+    FrameCall *call = nullptr;
+    explicit DevBuf(size_t want, FrameCall *fc = nullptr) : call(fc) {
         n = want ? want : 1;
         if (hipGetDevice(&dev) != hipSuccess) return;
         {
@@ -178,6 +190,7 @@ struct DevBuf {
             if (best != g_parked.size()) {
                 p = g_parked[best].p;
                 n = g_parked[best].n;
+                g_parked_bytes -= n;
                 g_parked.erase(g_parked.begin() + (long)best);
                 return;
             }
@@ -186,9 +199,14 @@ struct DevBuf {
     }
     ~DevBuf() {
         if (!p) return;
+        if (call && !call->idle) (void)call->sync();         // error exit with work in flight: wait before anyone reuses p
         {
             std::lock_guard<std::mutex> lock(g_park_mutex);
-            if (g_parked.size() < kMaxParked) { g_parked.push_back({p, n, dev}); return; }
+            if (g_parked.size() < kMaxParked && g_parked_bytes + n <= kMaxParkedBytes) {
+                g_parked.push_back({p, n, dev});
+                g_parked_bytes += n;
+                return;
+            }
         }
         (void)hipFree(p);
     }
@@ -202,6 +220,7 @@ extern "C" void zlz4_release_device_cache(void) {
     {
         std::lock_guard<std::mutex> lock(g_park_mutex);
         take.swap(g_parked);
+        g_parked_bytes = 0;
     }
     for (const ParkedBuf &b : take) (void)hipFree(b.p);
 }
@@ -294,31 +313,55 @@ __global__ __launch_bounds__(256) void k_frame_scatter(const uint8_t *__restrict
     if (block_checksum && t < 4) o[n + t] = (uint8_t)(cks[i] >> (8u * t));        // :425
 }
 
-// one lane: frame header at dst[0..), end mark and optional content checksum at dst[plan[0]..)
+// one lane: frame header at dst[0..) (hb.n = 0: none), then -- for the segment that ends the frame -- the end mark and the
+// optional content checksum at dst[plan[0]..)
 __global__ void k_frame_head_tail(HeaderBytes hb, uint8_t *dst, const int64_t *plan, const uint8_t *src, uint64_t n,
-                                  uint32_t content_checksum, int64_t *total_out) {
+                                  uint32_t tail, uint32_t content_checksum, int64_t *total_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (uint32_t k = 0; k < hb.n; k++) dst[k] = hb.b[k];
     uint64_t pos = (uint64_t)plan[0];
-    for (int k = 0; k < 4; k++) dst[pos + k] = 0;                                 // :433
-    pos += 4;
-    if (content_checksum) {
-        const uint32_t c = xxh32(src, n, 0);                                      // :384-386, :437-441
-        for (int k = 0; k < 4; k++) dst[pos + k] = (uint8_t)(c >> (8 * k));
+    if (tail) {
+        for (int k = 0; k < 4; k++) dst[pos + k] = 0;                             // :433
         pos += 4;
+        if (content_checksum) {
+            const uint32_t c = xxh32(src, n, 0);                                  // :384-386, :437-441
+            for (int k = 0; k < 4; k++) dst[pos + k] = (uint8_t)(c >> (8 * k));
+            pos += 4;
+        }
     }
     *total_out = (int64_t)pos;
 }
 
 // ------------------------------------------------------------------ decompress-side kernels
 // walk[0] = number of data blocks, walk[1] = srcPos after the walk, walk[2] = pending error code (0 = none),
-// The walk of src/lz4f.zig:563-600 without the payload work: block k's header position depends on all
-// earlier block sizes, so this is a serial chain of 4-byte reads.  Two uses: count (arrays null) and fill.
-__global__ void k_frame_walk(const uint8_t *__restrict__ src, uint64_t src_len, uint64_t src_pos, uint32_t block_checksum,
+// walk[3] = header size or header error, walk[4] = FLG byte, walk[5] = block size
+// The walk of src/lz4f.zig:563-600 without the payload work: block k's header position depends on all earlier block
+// sizes, so this is a serial chain of 4-byte reads (one lane).  The frame header is parsed here too (:547), so that
+// the host needs one read-back for header, block count and walk status.  Blocks beyond `max_blocks` are counted, not
+// recorded (the caller then repeats the walk with a larger table).
+// seg: bit 0 = the bytes start with a frame header; otherwise flg_in / bs_in describe the frame (a later rank's segment)
+__global__ void k_frame_walk(const uint8_t *__restrict__ src, uint64_t src_len, uint32_t seg, uint32_t flg_in, uint64_t bs_in,
                              uint64_t *__restrict__ data_off, uint32_t *__restrict__ data_len,
                              uint32_t *__restrict__ flags, uint64_t *__restrict__ cks_off, uint64_t max_blocks,
                              int64_t *__restrict__ walk) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t src_pos = 0;
+    uint32_t flg = flg_in;
+    uint64_t bs = bs_in;
+    walk[0] = 0; walk[1] = 0; walk[2] = 0; walk[3] = 0;
+    if (seg & 1u) {
+        uint8_t head[19];
+        const size_t have = src_len < sizeof head ? (size_t)src_len : sizeof head;
+        for (size_t k = 0; k < have; k++) head[k] = src[k];
+        const ParsedHeader ph = parse_header(head, have);                               // :547
+        walk[3] = ph.size;
+        if (ph.size < 0) { walk[4] = 0; walk[5] = 0; return; }
+        src_pos = (uint64_t)ph.size;
+        flg = ph.flg;
+        bs = ph.block_size;
+    }
+    walk[4] = flg; walk[5] = (int64_t)bs;
+    const uint32_t block_checksum = (flg & 0x10u) ? 1u : 0u;
     uint64_t nb = 0;
     int64_t err = 0;
     while (src_pos < src_len) {                                       // :563
@@ -336,7 +379,7 @@ __global__ void k_frame_walk(const uint8_t *__restrict__ src, uint64_t src_len, 
             if (src_pos + 4 > src_len) fl |= 2u;                      // FrameSizeWrong when this block is reached
             else { co = src_pos; src_pos += 4; }
         }
-        if (data_off && nb < max_blocks) { data_off[nb] = off; data_len[nb] = sz; flags[nb] = fl; cks_off[nb] = co; }
+        if (nb < max_blocks) { data_off[nb] = off; data_len[nb] = sz; flags[nb] = fl; cks_off[nb] = co; }
         nb++;
         if (fl & 2u) break;
     }
@@ -388,14 +431,58 @@ __global__ void k_dframe_plan(const uint32_t *__restrict__ data_len, const uint3
     dplan[0] = (int64_t)pos; dplan[1] = err;
 }
 
+// Speculative layout: every frame compressFrame writes has blocks that decode to exactly block_size bytes, except the
+// last one (:372-381), so block i can be decoded straight into dst + i * block_size with an exact capacity, without the
+// size pass.  k_dframe_check then proves the guess from the decoder's results; any deviation (a foreign frame with
+// short blocks, an error of any kind, a destination that is too small) sends the call to the exact two-pass plan.
+__global__ void k_dframe_spec(const uint32_t *__restrict__ data_len, const uint32_t *__restrict__ flags, uint32_t nblocks,
+                              uint64_t bs, uint64_t dst_cap, uint64_t *__restrict__ out_off, uint32_t *__restrict__ out_cap,
+                              uint32_t *__restrict__ dec_len) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += gridDim.x * blockDim.x) {
+        const uint64_t o = (uint64_t)i * bs;
+        out_off[i] = o < dst_cap ? o : dst_cap;
+        out_cap[i] = o >= dst_cap ? 0u : (uint32_t)((dst_cap - o) < bs ? (dst_cap - o) : bs);
+        dec_len[i] = (flags[i] & 1u) ? 0u : data_len[i];
+    }
+}
+
+// dplan[0] = total output bytes, dplan[1] = error (stays 0 here), dplan[2] = 1 if the speculative layout is proven
+__global__ __launch_bounds__(64) void k_dframe_check(const uint32_t *__restrict__ data_len, const uint32_t *__restrict__ flags,
+                                                     const int64_t *__restrict__ sizes, const uint32_t *__restrict__ cks_ok,
+                                                     const uint32_t *__restrict__ out_cap, uint32_t block_checksum,
+                                                     uint32_t nblocks, uint64_t bs, const int64_t *__restrict__ walk,
+                                                     int64_t *__restrict__ dplan) {
+    const uint32_t lane = threadIdx.x;
+    bool ok = walk[2] == 0;
+    uint64_t last = 0;
+    for (uint32_t i = lane; i < nblocks; i += 64u) {
+        if (block_checksum && cks_ok[i] != 1u) ok = false;
+        uint64_t sz;
+        if (flags[i] & 1u) { sz = data_len[i]; if (sz > out_cap[i]) ok = false; }
+        else { const int64_t r = sizes[i]; if (r < 0 || data_len[i] == 0) ok = false; sz = r < 0 ? 0 : (uint64_t)r; }
+        if (i + 1u < nblocks) { if (sz != bs) ok = false; }
+        else last = sz;
+    }
+    const bool all_ok = zlz4::ballot(!ok) == 0;
+    const uint32_t owner = nblocks ? (nblocks - 1u) & 63u : 0u;      // the lane that saw the last block
+    const uint64_t last_sz = ((uint64_t)zlz4::rdlane((uint32_t)(last >> 32), owner) << 32) | zlz4::rdlane((uint32_t)last, owner);
+    if (lane == 0) {
+        dplan[0] = nblocks ? (int64_t)((uint64_t)(nblocks - 1u) * bs + last_sz) : 0;
+        dplan[1] = 0;
+        dplan[2] = all_ok ? 1 : 0;
+    }
+}
+
 // one workgroup per block: raw copy of stored blocks (:607); compressed blocks are skipped here
 __global__ __launch_bounds__(256) void k_copy_stored(const uint8_t *__restrict__ src, const uint64_t *__restrict__ data_off,
                                                       const uint32_t *__restrict__ data_len,
                                                       const uint32_t *__restrict__ flags,
-                                                      const uint64_t *__restrict__ out_off, uint8_t *__restrict__ dst) {
+                                                      const uint64_t *__restrict__ out_off, uint8_t *__restrict__ dst,
+                                                      uint64_t dst_cap) {
     const uint32_t i = blockIdx.x, t = threadIdx.x;
     if (!(flags[i] & 1u)) return;
     const uint32_t n = data_len[i];
+    if (out_off[i] + n > dst_cap) return;               // (speculative layout: the check kernel reports it)
     const uint8_t *p = src + data_off[i];
     uint8_t *o = dst + out_off[i];
     for (uint32_t k = t * 16u; k + 16u <= n; k += 256u * 16u) zlz4::st128(o + k, zlz4::ld128(p + k));
@@ -412,9 +499,11 @@ __global__ void k_mask_stored(uint32_t *data_len_for_decode, const uint32_t *dat
     }
 }
 
-__global__ void k_content_check(const uint8_t *dst, uint64_t n, const uint8_t *stored, int64_t *dplan) {
+// content checksum over dst[0, total) with total read from the device (total_p[0]); only when no error is pending
+__global__ void k_content_check(const uint8_t *dst, const int64_t *total_p, const uint8_t *stored, int64_t *dplan) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (xxh32(dst, n, 0) != zx_rd32(stored)) dplan[1] = ZLZ4F_ERR_CONTENT_CHECKSUM_INVALID;   // :631
+    if (dplan[1] != 0) return;
+    if (xxh32(dst, (uint64_t)total_p[0], 0) != zx_rd32(stored)) dplan[1] = ZLZ4F_ERR_CONTENT_CHECKSUM_INVALID;   // :631
 }
 
 int64_t map_block_error(int64_t e) {     // mapCompressionError, src/lz4f.zig:144-149
@@ -455,14 +544,20 @@ int64_t zlz4f_header_size(const uint8_t *src, size_t n) {   // src/lz4f.zig:451-
     return size;
 }
 
-// src/lz4f.zig:354-446 on a device-resident source
-int64_t zlz4f_compress_frame_device(void *stream_, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap,
-                                    const zlz4f_prefs *prefs) {
-    const zlz4f_prefs p = prefs ? *prefs : kDefaultPrefs;
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t kSegFirst = 1u, kSegLast = 2u;
+
+// src/lz4f.zig:354-446 on a device-resident source.  seg: kSegFirst = write the frame header (:369), kSegLast = write the
+// end mark (:433) and the content checksum (:437-441); a whole frame has both.
+int64_t compress_frame_impl(hipStream_t st, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, const zlz4f_prefs &p,
+                            uint32_t seg) {
     if (cap < zlz4f_compress_frame_bound(n, &p)) return ZLZ4F_ERR_DST_MAX_SIZE_TOO_SMALL;   // :363-366
     if (!gfx950_ok()) return ZLZ4_ERR_DEVICE;
-    hipStream_t st = (hipStream_t)stream_;
-    const HeaderBytes hb = encode_header(p);                                               // :369
+    HeaderBytes hb = encode_header(p);                                                     // :369
+    if (!(seg & kSegFirst)) hb.n = 0;
     const size_t bs = block_size_of(p.block_size_id);                                      // :372
     const uint64_t nb64 = (n + bs - 1) / bs;
     if (nb64 > 0x7FFFFFFFull) return ZLZ4F_ERR_SRC_SIZE_TOO_LARGE;
@@ -472,24 +567,32 @@ int64_t zlz4f_compress_frame_device(void *stream_, const uint8_t *d_src, size_t 
     if (p.compression_level > 0) {
         hc_level = p.compression_level < 2 ? 9 : (p.compression_level > 12 ? 12 : p.compression_level);
     }
+    const uint32_t tail = (seg & kSegLast) ? 1u : 0u;
+    const uint32_t content_checksum = (tail && p.content_checksum == 1) ? 1u : 0u;
     const uint64_t slot = (zlz4_compress_bound(bs) + 15) & ~15ull;
-    DevBuf d_plan(4 * sizeof(int64_t));
+    FrameCall fc(st);
+    DevBuf d_plan(4 * sizeof(int64_t), &fc);
     if (!d_plan.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
     int64_t total = 0;
     if (nb == 0) {
         int64_t plan0[3] = {(int64_t)hb.n, 0, 0};
-        if (hipMemcpy(d_plan.p, plan0, sizeof plan0, hipMemcpyHostToDevice) != hipSuccess) return ZLZ4_ERR_DEVICE;
+        if (hipMemcpyAsync(d_plan.p, plan0, sizeof plan0, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+        fc.launched();
         hipLaunchKernelGGL(k_frame_head_tail, dim3(1), dim3(64), 0, st, hb, d_dst, d_plan.as<int64_t>(), d_src,
-                           (uint64_t)n, p.content_checksum == 1 ? 1u : 0u, d_plan.as<int64_t>() + 3);
-        if (hipMemcpyAsync(&total, d_plan.as<int64_t>() + 3, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+                           (uint64_t)n, tail, content_checksum, d_plan.as<int64_t>() + 3);
+        if (hipMemcpyAsync(&total, d_plan.as<int64_t>() + 3, 8, hipMemcpyDeviceToHost, st) != hipSuccess || !fc.sync())
+            return ZLZ4_ERR_DEVICE;
         return total;
     }
-    DevBuf d_slots((uint64_t)nb * slot), d_u64((uint64_t)nb * 3 * sizeof(uint64_t)), d_u32((uint64_t)nb * 4 * sizeof(uint32_t)),
-        d_res((uint64_t)nb * sizeof(int64_t));
+    DevBuf d_slots((uint64_t)nb * slot, &fc), d_u64((uint64_t)nb * 3 * sizeof(uint64_t), &fc),
+        d_u32((uint64_t)nb * 4 * sizeof(uint32_t), &fc), d_res((uint64_t)nb * sizeof(int64_t), &fc);
     if (!d_slots.p || !d_u64.p || !d_u32.p || !d_res.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
+    const size_t wsb = hc_level ? zlz4_hc_workspace_bytes(nb, (uint32_t)bs) : 0;
+    DevBuf d_ws(wsb, &fc);
+    if (hc_level && !d_ws.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
     uint64_t *in_off = d_u64.as<uint64_t>(), *out_off = in_off + nb, *dst_off = out_off + nb;
     uint32_t *in_len = d_u32.as<uint32_t>(), *out_cap = in_len + nb, *hdr = out_cap + nb, *cks = hdr + nb;
+    fc.launched();
     hipLaunchKernelGGL(k_frame_desc, dim3((nb + 255) / 256 > 1024 ? 1024 : (nb + 255) / 256), dim3(256), 0, st, (uint64_t)n,
                        (uint64_t)bs, slot, nb, in_off, in_len, out_off, out_cap);
     int rc;
@@ -497,12 +600,8 @@ int64_t zlz4f_compress_frame_device(void *stream_, const uint8_t *d_src, size_t 
         rc = zlz4_launch_compress_fast(st, d_src, in_off, in_len, d_slots.as<uint8_t>(), out_off, out_cap,
                                        d_res.as<int64_t>(), nb, (uint32_t)bs, 1);                        // :400-404
     } else {
-        const size_t wsb = zlz4_hc_workspace_bytes(nb, (uint32_t)bs);
-        DevBuf d_ws(wsb);
-        if (!d_ws.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
         rc = zlz4_launch_compress_hc(st, d_src, in_off, in_len, d_slots.as<uint8_t>(), out_off, out_cap,
                                      d_res.as<int64_t>(), nb, (uint32_t)bs, hc_level, d_ws.p, wsb);      // :394-398
-        if (hipStreamSynchronize(st) != hipSuccess) return ZLZ4_ERR_DEVICE;   // workspace is freed at scope end
     }
     if (rc != 0) return rc;
     hipLaunchKernelGGL(k_frame_plan, dim3(1), dim3(64), 0, st, d_res.as<int64_t>(), in_len, nb,
@@ -513,13 +612,147 @@ int64_t zlz4f_compress_frame_device(void *stream_, const uint8_t *d_src, size_t 
     hipLaunchKernelGGL(k_frame_scatter, dim3(nb), dim3(256), 0, st, d_src, in_off, d_slots.as<uint8_t>(), out_off, hdr,
                        dst_off, cks, p.block_checksum == 1 ? 1u : 0u, d_dst);
     hipLaunchKernelGGL(k_frame_head_tail, dim3(1), dim3(64), 0, st, hb, d_dst, d_plan.as<int64_t>(), d_src, (uint64_t)n,
-                       p.content_checksum == 1 ? 1u : 0u, d_plan.as<int64_t>() + 3);
+                       tail, content_checksum, d_plan.as<int64_t>() + 3);
     int64_t plan[4];
-    if (hipMemcpyAsync(plan, d_plan.p, sizeof plan, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+    if (hipMemcpyAsync(plan, d_plan.p, sizeof plan, hipMemcpyDeviceToHost, st) != hipSuccess || !fc.sync() ||
+        hipGetLastError() != hipSuccess)
         return ZLZ4_ERR_DEVICE;
     if (plan[1] != 0) return map_block_error(plan[2]);                                                   // :398, :404
     return plan[3];
+}
+
+// src/lz4f.zig:541-638 on device-resident bytes.  seg & kSegFirst: the bytes start with the frame header (:547), else
+// `p` describes the frame (block checksum flag, block size).  A whole frame has kSegFirst | kSegLast; without kSegLast
+// the bytes are expected to end after a block (no end mark, no content checksum).
+int64_t decompress_frame_impl(hipStream_t st, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, const zlz4f_prefs &p,
+                              uint32_t seg) {
+    if (!gfx950_ok()) return ZLZ4_ERR_DEVICE;
+    FrameCall fc(st);
+    DevBuf d_walk(12 * sizeof(int64_t), &fc);
+    if (!d_walk.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
+    int64_t *walk = d_walk.as<int64_t>(), *dplan = walk + 8;
+    const uint32_t flg_in = 0x40u | (p.block_mode == 1 ? 0x20u : 0u) | (p.block_checksum == 1 ? 0x10u : 0u);
+    const uint64_t bs_in = block_size_of(p.block_size_id);
+    // the block table is sized for the blocks a frame of this length usually has; a frame of tiny blocks repeats the walk
+    uint64_t table_cap = n / 1024 + 64;
+    if (table_cap > n / 5 + 1) table_cap = n / 5 + 1;
+    int64_t w[6];
+    for (int attempt = 0;; attempt++) {
+        DevBuf d_u64(table_cap * 3 * sizeof(uint64_t), &fc), d_u32(table_cap * 5 * sizeof(uint32_t), &fc),
+            d_sz(table_cap * sizeof(int64_t), &fc);
+        if (!d_u64.p || !d_u32.p || !d_sz.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
+        uint64_t *data_off = d_u64.as<uint64_t>(), *cks_off = data_off + table_cap, *out_off = cks_off + table_cap;
+        uint32_t *data_len = d_u32.as<uint32_t>(), *flags = data_len + table_cap, *cks_ok = flags + table_cap,
+                 *out_cap = cks_ok + table_cap, *dec_len = out_cap + table_cap;
+        fc.launched();
+        hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, st, d_src, (uint64_t)n, seg, flg_in, bs_in, data_off, data_len,
+                           flags, cks_off, table_cap, walk);
+        if (hipMemcpyAsync(w, walk, sizeof w, hipMemcpyDeviceToHost, st) != hipSuccess || !fc.sync()) return ZLZ4_ERR_DEVICE;
+        if (w[3] < 0) return w[3];                                                                       // header error :547
+        if (w[0] > 0x7FFFFFFFll) return ZLZ4F_ERR_FRAME_SIZE_WRONG;
+        if ((uint64_t)w[0] > table_cap) {
+            if (attempt) return ZLZ4_ERR_DEVICE;
+            table_cap = (uint64_t)w[0];
+            continue;
+        }
+        const uint32_t nb = (uint32_t)w[0];
+        const uint64_t src_pos_end = (uint64_t)w[1];
+        const int64_t walk_err = w[2];
+        const uint32_t flg = (uint32_t)w[4];
+        const uint64_t bs = (uint64_t)w[5];
+        const uint32_t bc = (flg & 0x10) ? 1u : 0u, cc = ((seg & kSegLast) && (flg & 0x04)) ? 1u : 0u;
+        int64_t plan_host[3] = {0, walk_err, 0};
+        const uint32_t gridb = (nb + 255) / 256 > 1024 ? 1024 : (nb + 255) / 256;
+        if (nb) {
+            // speculative single pass: block i -> dst + i * block_size, proven afterwards
+            fc.launched();
+            if (bc) hipLaunchKernelGGL(k_block_verify, dim3((nb + 63) / 64), dim3(64), 0, st, d_src, data_off, data_len, flags,
+                                       cks_off, nb, cks_ok);
+            hipLaunchKernelGGL(k_dframe_spec, dim3(gridb), dim3(256), 0, st, data_len, flags, nb, bs, (uint64_t)cap, out_off,
+                               out_cap, dec_len);
+            int rc = zlz4_launch_decompress_safe(st, d_src, data_off, dec_len, d_dst, out_off, out_cap, d_sz.as<int64_t>(), nb);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(k_copy_stored, dim3(nb), dim3(256), 0, st, d_src, data_off, data_len, flags, out_off, d_dst,
+                               (uint64_t)cap);
+            hipLaunchKernelGGL(k_dframe_check, dim3(1), dim3(64), 0, st, data_len, flags, d_sz.as<int64_t>(), cks_ok, out_cap, bc,
+                               nb, bs, walk, dplan);
+            if (cc && src_pos_end + 4 <= n)     // only meaningful when the guess holds; checked below
+                hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan);
+            if (hipMemcpyAsync(plan_host, dplan, sizeof plan_host, hipMemcpyDeviceToHost, st) != hipSuccess || !fc.sync())
+                return ZLZ4_ERR_DEVICE;
+            if (plan_host[2] == 1) {
+                if (cc && src_pos_end + 4 > n) return ZLZ4F_ERR_FRAME_SIZE_WRONG;                        // :626
+                if (hipGetLastError() != hipSuccess) return ZLZ4_ERR_DEVICE;
+                return plan_host[1] != 0 ? plan_host[1] : plan_host[0];
+            }
+            // exact plan: size pass (unlimited capacity), the serial dstPos accumulation with the reference's error
+            // order (:602-621), then decode + raw copies at the exact places
+            DevBuf d_x64((uint64_t)nb * sizeof(uint64_t), &fc), d_x32((uint64_t)nb * sizeof(uint32_t), &fc);
+            if (!d_x64.p || !d_x32.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
+            uint64_t *zero_off = d_x64.as<uint64_t>();
+            uint32_t *big_cap = d_x32.as<uint32_t>();
+            fc.launched();
+            hipLaunchKernelGGL(k_mask_stored, dim3(gridb), dim3(256), 0, st, dec_len, data_len, flags, nb, zero_off, big_cap);
+            rc = zlz4_launch_decompress_sizes(st, d_src, data_off, dec_len, zero_off, big_cap, d_sz.as<int64_t>(), nb);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(k_dframe_plan, dim3(1), dim3(64), 0, st, data_len, flags, d_sz.as<int64_t>(), cks_ok, bc, nb,
+                               (uint64_t)cap, walk_err, out_off, out_cap, dplan);
+            if (hipMemcpyAsync(plan_host, dplan, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || !fc.sync())
+                return ZLZ4_ERR_DEVICE;
+            if (plan_host[1] != 0) return plan_host[1];
+            fc.launched();
+            rc = zlz4_launch_decompress_safe(st, d_src, data_off, dec_len, d_dst, out_off, out_cap, d_sz.as<int64_t>(), nb);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(k_copy_stored, dim3(nb), dim3(256), 0, st, d_src, data_off, data_len, flags, out_off, d_dst,
+                               (uint64_t)cap);
+        } else if (walk_err != 0) {
+            return walk_err;
+        }
+        if (cc) {                                                                                        // :625-635
+            if (src_pos_end + 4 > n) { (void)fc.sync(); return ZLZ4F_ERR_FRAME_SIZE_WRONG; }
+            int64_t tot[2] = {plan_host[0], 0};
+            if (hipMemcpyAsync(dplan, tot, sizeof tot, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+            fc.launched();
+            hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan);
+            if (hipMemcpyAsync(plan_host, dplan, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+        }
+        if (!fc.sync() || hipGetLastError() != hipSuccess) return ZLZ4_ERR_DEVICE;
+        if (plan_host[1] != 0) return plan_host[1];
+        return plan_host[0];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t zlz4f_compress_frame_device(void *stream_, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap,
+                                    const zlz4f_prefs *prefs) {
+    return compress_frame_impl((hipStream_t)stream_, d_src, n, d_dst, cap, prefs ? *prefs : kDefaultPrefs, kSegFirst | kSegLast);
+}
+
+// One rank's part of a frame whose blocks are spread over several GPUs (the block loop :379-430 carries no state)
+int64_t zlz4f_compress_frame_segment_device(void *stream_, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap,
+                                            const zlz4f_prefs *prefs, uint32_t segment_flags) {
+    const zlz4f_prefs p = prefs ? *prefs : kDefaultPrefs;
+    if (segment_flags & ~(kSegFirst | kSegLast)) return ZLZ4F_ERR_PARAMETER_INVALID;
+    // XXH32 of the whole content is one serial chain over every rank's bytes: not available for a split frame
+    if (p.content_checksum == 1 && segment_flags != (kSegFirst | kSegLast)) return ZLZ4_ERR_UNSUPPORTED;
+    const size_t bs = block_size_of(p.block_size_id);
+    if (!(segment_flags & kSegLast) && n % bs != 0) return ZLZ4F_ERR_PARAMETER_INVALID;   // only the last block may be short
+    return compress_frame_impl((hipStream_t)stream_, d_src, n, d_dst, cap, p, segment_flags);
+}
+
+int64_t zlz4f_decompress_frame_device(void *stream_, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap) {
+    return decompress_frame_impl((hipStream_t)stream_, d_src, n, d_dst, cap, kDefaultPrefs, kSegFirst | kSegLast);
+}
+
+int64_t zlz4f_decompress_frame_segment_device(void *stream_, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap,
+                                              const zlz4f_prefs *prefs, uint32_t segment_flags) {
+    const zlz4f_prefs p = prefs ? *prefs : kDefaultPrefs;
+    if (segment_flags & ~(kSegFirst | kSegLast)) return ZLZ4F_ERR_PARAMETER_INVALID;
+    if (p.content_checksum == 1 && segment_flags != (kSegFirst | kSegLast)) return ZLZ4_ERR_UNSUPPORTED;
+    return decompress_frame_impl((hipStream_t)stream_, d_src, n, d_dst, cap, p, segment_flags);
 }
 
 // src/lz4f.zig:354-446, host pointers: stage -> device path -> copy the frame back
@@ -536,70 +769,6 @@ int64_t zlz4f_compress_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t 
     if ((uint64_t)r > cap) return ZLZ4_ERR_DEVICE;
     if (hipMemcpy(dst, d_dst.p, (size_t)r, hipMemcpyDeviceToHost) != hipSuccess) return ZLZ4_ERR_DEVICE;
     return r;
-}
-
-// src/lz4f.zig:541-638 on a device-resident frame
-int64_t zlz4f_decompress_frame_device(void *stream_, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap) {
-    if (!gfx950_ok()) return ZLZ4_ERR_DEVICE;
-    hipStream_t st = (hipStream_t)stream_;
-    uint8_t head[19];
-    const size_t have = n < sizeof head ? n : sizeof head;
-    if (have && (hipMemcpyAsync(head, d_src, have, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                 hipStreamSynchronize(st) != hipSuccess)) return ZLZ4_ERR_DEVICE;
-    const ParsedHeader ph = parse_header(head, have);                                                    // :547
-    if (ph.size < 0) return ph.size;
-    const uint32_t bc = (ph.flg & 0x10) ? 1u : 0u, cc = (ph.flg & 0x04) ? 1u : 0u;
-    DevBuf d_walk(8 * sizeof(int64_t));
-    if (!d_walk.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
-    int64_t *walk = d_walk.as<int64_t>(), *dplan = walk + 4;
-    // pass 1: count blocks
-    hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, st, d_src, (uint64_t)n, (uint64_t)ph.size, bc,
-                       (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, walk);
-    int64_t w[3];
-    if (hipMemcpyAsync(w, walk, sizeof w, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return ZLZ4_ERR_DEVICE;
-    if (w[0] > 0x7FFFFFFFll) return ZLZ4F_ERR_FRAME_SIZE_WRONG;
-    const uint32_t nb = (uint32_t)w[0];
-    const uint64_t src_pos_end = (uint64_t)w[1];
-    const int64_t walk_err = w[2];
-    int64_t plan_host[2] = {0, walk_err};
-    DevBuf d_u64((uint64_t)(nb ? nb : 1) * 4 * sizeof(uint64_t)), d_u32((uint64_t)(nb ? nb : 1) * 6 * sizeof(uint32_t)),
-        d_sz((uint64_t)(nb ? nb : 1) * sizeof(int64_t));
-    if (!d_u64.p || !d_u32.p || !d_sz.p) return ZLZ4F_ERR_ALLOCATION_FAILED;
-    uint64_t *data_off = d_u64.as<uint64_t>(), *cks_off = data_off + nb, *out_off = cks_off + nb, *zero_off = out_off + nb;
-    uint32_t *data_len = d_u32.as<uint32_t>(), *flags = data_len + nb, *cks_ok = flags + nb, *out_cap = cks_ok + nb,
-             *dec_len = out_cap + nb, *big_cap = dec_len + nb;
-    if (nb) {
-        // pass 2: fill the block table
-        hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, st, d_src, (uint64_t)n, (uint64_t)ph.size, bc, data_off,
-                           data_len, flags, cks_off, (uint64_t)nb, walk);
-        if (bc) hipLaunchKernelGGL(k_block_verify, dim3((nb + 63) / 64), dim3(64), 0, st, d_src, data_off, data_len, flags,
-                                   cks_off, nb, cks_ok);
-        hipLaunchKernelGGL(k_mask_stored, dim3((nb + 255) / 256 > 1024 ? 1024 : (nb + 255) / 256), dim3(256), 0, st, dec_len,
-                           data_len, flags, nb, zero_off, big_cap);
-        // size pass (unlimited capacity), then the serial dstPos plan, then decode + raw copies
-        int rc = zlz4_launch_decompress_sizes(st, d_src, data_off, dec_len, zero_off, big_cap, d_sz.as<int64_t>(), nb);
-        if (rc != 0) return rc;
-    }
-    hipLaunchKernelGGL(k_dframe_plan, dim3(1), dim3(64), 0, st, data_len, flags, d_sz.as<int64_t>(), cks_ok, bc, nb,
-                       (uint64_t)cap, walk_err, out_off, out_cap, dplan);
-    if (hipMemcpyAsync(plan_host, dplan, sizeof plan_host, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) return ZLZ4_ERR_DEVICE;
-    if (plan_host[1] != 0) return plan_host[1];
-    if (nb) {
-        int rc = zlz4_launch_decompress_safe(st, d_src, data_off, dec_len, d_dst, out_off, out_cap, d_sz.as<int64_t>(), nb);
-        if (rc != 0) return rc;
-        hipLaunchKernelGGL(k_copy_stored, dim3(nb), dim3(256), 0, st, d_src, data_off, data_len, flags, out_off, d_dst);
-    }
-    if (cc) {                                                                                            // :625-635
-        if (src_pos_end + 4 > n) { (void)hipStreamSynchronize(st); return ZLZ4F_ERR_FRAME_SIZE_WRONG; }
-        hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, (uint64_t)plan_host[0], d_src + src_pos_end,
-                           dplan);
-        if (hipMemcpyAsync(plan_host, dplan, sizeof plan_host, hipMemcpyDeviceToHost, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
-    }
-    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return ZLZ4_ERR_DEVICE;
-    if (plan_host[1] != 0) return plan_host[1];
-    return plan_host[0];
 }
 
 // src/lz4f.zig:541-638, host pointers
