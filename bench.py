@@ -200,15 +200,20 @@ def main():
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         fsize = [0]
 
+        # One logical frame of world x nblocks blocks: rank r holds blocks [r*nblocks, (r+1)*nblocks) (shard.shard_range)
+        # and produces / decodes its own segment of the frame; rank 0's segment starts with the frame header, the last
+        # rank's ends with the end mark.  With one rank the segment is the whole frame.
+        seg_flags = (zl.lz4f.SEG_FIRST if rank == 0 else 0) | (zl.lz4f.SEG_LAST if rank == world - 1 else 0)
+
         def do_compress():
-            r = L.zlz4f_compress_frame_device(st, C.c_void_p(inp.data_ptr()), total_n, C.c_void_p(frame.data_ptr()),
-                                              bound, C.byref(prefs))
+            r = L.zlz4f_compress_frame_segment_device(st, C.c_void_p(inp.data_ptr()), total_n, C.c_void_p(frame.data_ptr()),
+                                                      bound, C.byref(prefs), seg_flags)
             assert r > 0, "compressFrame failed: %s" % zl.error_name(r)
             fsize[0] = r
 
         def do_decompress():
-            r = L.zlz4f_decompress_frame_device(st, C.c_void_p(frame.data_ptr()), fsize[0], C.c_void_p(out.data_ptr()),
-                                                total_n)
+            r = L.zlz4f_decompress_frame_segment_device(st, C.c_void_p(frame.data_ptr()), fsize[0], C.c_void_p(out.data_ptr()),
+                                                        total_n, C.byref(prefs), seg_flags)
             assert r == total_n, "decompressFrame failed: %s" % zl.error_name(r)
 
         do_compress()
@@ -216,6 +221,13 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(out, inp), "frame round trip mismatch"
         total_c = fsize[0]
+        if dist_on:
+            # the only cross-rank step of the real flow: where each segment goes in the assembled frame (untimed here)
+            from zig_lz4_amd import shard
+            sizes = [torch.zeros(1, dtype=torch.int64, device="cpu" if rehearse else dev) for _ in range(world)]
+            td.all_gather(sizes, torch.tensor([fsize[0]], dtype=torch.int64, device="cpu" if rehearse else dev))
+            offs, end = shard.segment_offsets([int(x) for x in sizes], 0)
+            log("[rank %d] segment %d bytes at frame offset %d of %d" % (rank, fsize[0], offs[rank], end))
         sample_src = inp.reshape(nblocks, block)
         csize_head = None
     elif decomp_only:
@@ -338,7 +350,10 @@ def main():
         value = world * total_n * args.steps / elapsed / GIB
         comp_gibs = None if decomp_only else total_n / (tc_ms * 1e-3) / GIB
         dec_gibs = total_n / (td_ms * 1e-3) / GIB
-        kc = {"cfg2": "zlz4::k_compress_fast<uint16_t>", "cfg4": "zlz4::k_hc_search<uint16_t,uint32_t>",
+        hc_kernels = ("zlz4::k_hc_mid_serial" if args.level <= 2 else
+                      "HC pipeline: k_hc_build_links + k_hc_seg_search<4> + k_hc_parse_emit (x4 rounds of 4096 blocks)" if args.level <= 9 else
+                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse (x4 rounds of 4096 blocks)")
+        kc = {"cfg2": "zlz4::k_compress_fast<uint16_t>", "cfg4": hc_kernels,
               "cfg5": "zlz4::k_compress_fast<uint32_t>", "cfg3": None}[args.workload]
         if decomp_only:
             dom, dom_ms = "zlz4::k_decompress_safe<true>", td_ms
@@ -368,7 +383,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic.get("decompress" if decomp_only else "compress"),
-                         "traffic_source": traffic.get("source"),
+                         "traffic_source": (None if not traffic else
+                                            "from profile, not measured in this run: " + str(traffic.get("source"))),
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms},
             "roofline_decompress": {"bound": "hbm", "kernel": "zlz4::k_decompress_safe<true>",
                                     "achieved": algo / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -96,6 +96,18 @@ int64_t zlz4_compress_fast(const uint8_t *src, size_t src_len, uint8_t *dst, siz
 int64_t zlz4_compress_hc(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                          int32_t compression_level);
 
+/* replaces lz4hc.sizeofStateHC, src/lz4hc.zig:1492-1494 (= @sizeOf(Context), tables + scalars) */
+size_t  zlz4_sizeof_state_hc(void);
+
+/* replaces lz4hc.compressHCExtState, src/lz4hc.zig:1457-1489, for a context in its initial state (Context.init(),
+ * :405-419 -- what compressHC itself passes, :1450): level < 1 -> 9, level 1 -> lz4mid, > 12 -> 12; dst_cap == 0 ->
+ * OutputTooSmall.  The device keeps its tables in LDS / its own workspace: `state` is only validated (non-null,
+ * >= zlz4_sizeof_state_hc() bytes, else InvalidState) and never read or written, so a context that still holds the
+ * tables of an earlier call (the reference would search them, :1001-1006 resets only the index base) is treated as
+ * fresh -- carrying history from call to call is the streaming API, which is out of scope. */
+int64_t zlz4_compress_hc_ext_state(void *state, size_t state_len, const uint8_t *src, size_t src_len,
+                                   uint8_t *dst, size_t dst_cap, int32_t compression_level);
+
 /* replaces lz4.decompressSafe, src/lz4.zig:257-259 (decompressGeneric :89-251, no dict) */
 int64_t zlz4_decompress_safe(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap);
 

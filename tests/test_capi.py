@@ -90,6 +90,6 @@ def test_cpp_host_mirror_compiles_links_and_runs(zl, tmp_path):
     exe = str(tmp_path / "hmc")
     libdir = os.path.dirname(zl.LIB_PATH)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host_mirror_check.cpp"),
-                           "-L", libdir, "-lzlz4_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", libdir, "-lzlz4_amd", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr

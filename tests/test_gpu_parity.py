@@ -246,3 +246,18 @@ def test_batch_max_in_len_understated(zl, oracle, gpu):
             else:
                 want = oracle.compress_default(b) if kind == "fast" else oracle.compress_hc(b, level)
                 assert r[i] == len(want) and bytes(o[out_offs[i]: out_offs[i] + r[i]]) == want, (kind, level, lie, i)
+
+
+def test_compress_hc_ext_state(zl, oracle, gpu):
+    """lz4hc.compressHCExtState / sizeofStateHC (src/lz4hc.zig:1457-1494) with a fresh context: the level rules differ
+    from compressHC's (level < 1 -> 9, level 1 -> the table's lz4mid row, > 12 -> 12; dst.len == 0 -> OutputTooSmall)."""
+    n_state = zl.sizeofStateHC()
+    assert n_state >= 32768 * 4 + 65536 * 2
+    b = bytes(dg.text_bytes(30000, 77))
+    for level, same_as in ((9, 9), (0, 9), (-3, 9), (1, 2), (2, 2), (3, 3), (12, 12), (40, 12)):
+        assert zl.compressHCExtState(n_state, b, level) == oracle.compress_hc(b, same_as), level
+    assert zl.compressHCExtState(n_state, b"", 9) == b""
+    for bad_state, cap, name in ((n_state - 1, None, "InvalidState"), (n_state, 0, "OutputTooSmall")):
+        with pytest.raises(zl.Lz4Error) as e:
+            zl.compressHCExtState(bad_state, b, 9, dst_cap=cap)
+        assert e.value.name == name

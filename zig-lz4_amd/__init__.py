@@ -58,6 +58,8 @@ SYMBOLS = {
     "zlz4_compress_default": (_I64, [_VP, _SZ, _VP, _SZ]),
     "zlz4_compress_fast": (_I64, [_VP, _SZ, _VP, _SZ, _U32]),
     "zlz4_compress_hc": (_I64, [_VP, _SZ, _VP, _SZ, _I32]),
+    "zlz4_sizeof_state_hc": (_SZ, []),
+    "zlz4_compress_hc_ext_state": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ, _I32]),
     "zlz4_decompress_safe": (_I64, [_VP, _SZ, _VP, _SZ]),
     "zlz4_decompress_safe_partial": (_I64, [_VP, _SZ, _VP, _SZ, _SZ]),
     "zlz4_sizeof_state": (_SZ, []),
@@ -157,6 +159,21 @@ def compressHC(src, compression_level, dst_cap=None):
     """lz4hc.compressHC(src, dst, level), src/lz4hc.zig:1440-1453."""
     cap = compressBound(len(src)) if dst_cap is None else dst_cap
     return _run(lib().zlz4_compress_hc, src, cap, compression_level)
+
+
+def sizeofStateHC():
+    """lz4hc.sizeofStateHC, src/lz4hc.zig:1492-1494."""
+    return lib().zlz4_sizeof_state_hc()
+
+
+def compressHCExtState(state_len, src, compression_level, dst_cap=None):
+    """lz4hc.compressHCExtState(ctx, src, dst, level), src/lz4hc.zig:1457-1489 (fresh context, given by its size)."""
+    cap = compressBound(len(src)) if dst_cap is None else dst_cap
+    s, n = _in(src)
+    st = (C.c_uint8 * max(1, state_len))()
+    d = (C.c_uint8 * max(1, cap))()
+    r = _check(lib().zlz4_compress_hc_ext_state(C.addressof(st), state_len, C.addressof(s), n, C.addressof(d), cap, compression_level))
+    return bytes(d[:r])
 
 
 def decompressSafe(src, dst_cap):

@@ -58,6 +58,35 @@ inline Result compressHC(const std::uint8_t *src, std::size_t n, std::uint8_t *d
     return wrap(zlz4_compress_hc(src, n, dst, cap, level));
 }
 
+// lz4hc.sizeofStateHC / compressHCExtState, src/lz4hc.zig:1457-1494 (fresh context, passed as the bytes it occupies)
+inline std::size_t sizeofStateHC() { return zlz4_sizeof_state_hc(); }
+inline Result compressHCExtState(void *ctx, std::size_t ctx_len, const std::uint8_t *src, std::size_t n, std::uint8_t *dst,
+                                 std::size_t cap, std::int32_t level) {
+    return wrap(zlz4_compress_hc_ext_state(ctx, ctx_len, src, n, dst, cap, level));
+}
+
+// The hot path itself: many independent blocks per call, DEVICE pointers, asynchronous on `stream` (hipStream_t as
+// void*).  A host-side slice-of-slices becomes the four descriptor arrays (they live in device memory too).
+namespace device {
+struct Blocks {
+    const std::uint8_t *in; const std::uint64_t *in_off; const std::uint32_t *in_len;
+    std::uint8_t *out; const std::uint64_t *out_off; const std::uint32_t *out_cap;
+    std::int64_t *result; std::uint32_t nblocks;
+};
+inline Result compressFastBatch(void *stream, const Blocks &b, std::uint32_t max_in_len, std::uint32_t accel = 1) {
+    return wrap(zlz4_batch_compress_fast(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks, max_in_len, accel));
+}
+inline Result decompressSafeBatch(void *stream, const Blocks &b) {
+    return wrap(zlz4_batch_decompress_safe(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks));
+}
+inline std::size_t compressHCWorkspace(std::uint32_t nblocks, std::uint32_t max_in_len) {
+    return zlz4_batch_compress_hc_workspace(nblocks, max_in_len);
+}
+inline Result compressHCBatch(void *stream, const Blocks &b, std::uint32_t max_in_len, std::int32_t level, void *ws, std::size_t ws_bytes) {
+    return wrap(zlz4_batch_compress_hc(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks, max_in_len, level, ws, ws_bytes));
+}
+}  // namespace device
+
 namespace lz4f {   // src/lz4f.zig
 using Preferences = zlz4f_prefs;
 constexpr std::uint32_t MAGICNUMBER = ZLZ4F_MAGICNUMBER;
@@ -69,6 +98,19 @@ inline Result decompressFrame(const std::uint8_t *src, std::size_t n, std::uint8
     return wrap(zlz4f_decompress_frame(src, n, dst, cap));
 }
 inline Result headerSize(const std::uint8_t *src, std::size_t n) { return wrap(zlz4f_header_size(src, n)); }
+// device-resident frames and per-rank frame segments (BASELINE configs[4])
+inline Result compressFrameDevice(void *stream, const std::uint8_t *d_src, std::size_t n, std::uint8_t *d_dst, std::size_t cap, const Preferences *p = nullptr) {
+    return wrap(zlz4f_compress_frame_device(stream, d_src, n, d_dst, cap, p));
+}
+inline Result decompressFrameDevice(void *stream, const std::uint8_t *d_src, std::size_t n, std::uint8_t *d_dst, std::size_t cap) {
+    return wrap(zlz4f_decompress_frame_device(stream, d_src, n, d_dst, cap));
+}
+inline Result compressFrameSegmentDevice(void *stream, const std::uint8_t *d_src, std::size_t n, std::uint8_t *d_dst, std::size_t cap, const Preferences *p, std::uint32_t seg) {
+    return wrap(zlz4f_compress_frame_segment_device(stream, d_src, n, d_dst, cap, p, seg));
+}
+inline Result decompressFrameSegmentDevice(void *stream, const std::uint8_t *d_src, std::size_t n, std::uint8_t *d_dst, std::size_t cap, const Preferences *p, std::uint32_t seg) {
+    return wrap(zlz4f_decompress_frame_segment_device(stream, d_src, n, d_dst, cap, p, seg));
+}
 }  // namespace lz4f
 
 }  // namespace zlz4

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/zlz4_amd.h"
+#include "zlz4_host.hpp"
 
 // kernel launchers (one per .hip file)
 extern "C" int zlz4_launch_decompress_safe(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
@@ -45,15 +46,8 @@ bool device_ok() {
     return g_device_ok == 0;
 }
 
-// RAII device allocation
-struct DevBuf {
-    void *p = nullptr;
-    explicit DevBuf(size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) p = nullptr; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    template <typename T> T *as() const { return static_cast<T *>(p); }
-};
+using zlz4host::DevBuf;
+using zlz4host::DeviceCall;
 
 enum class Op { Fast, Hc, Decompress };
 
@@ -67,11 +61,16 @@ int64_t run_single(Op op, const uint8_t *src, size_t src_len, uint8_t *dst, size
     const uint32_t cap32 = dst_cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dst_cap;
     const uint32_t len32 = (uint32_t)src_len;
 
-    DevBuf d_in(src_len), d_out(cap32), d_meta(64);
-    if (!d_in.p || !d_out.p || !d_meta.p) return ZLZ4_ERR_ALLOCATION_FAILED;
+    // scratch from the parked-buffer cache (zlz4_host.hpp): a caller that loops over single blocks does not pay a
+    // hipMalloc / hipFree pair per call
+    hipStream_t st = nullptr;
+    DeviceCall dc(st);
+    const size_t ws = op == Op::Hc ? zlz4_hc_workspace_bytes(1, len32) : 0;
+    DevBuf d_in(src_len, &dc), d_out(cap32, &dc), d_meta(64, &dc), d_ws(ws, &dc);
+    if (!d_in.p || !d_out.p || !d_meta.p || !d_ws.p) return ZLZ4_ERR_ALLOCATION_FAILED;
     struct Meta { uint64_t in_off; uint64_t out_off; int64_t result; uint32_t in_len; uint32_t out_cap; } m;
     m.in_off = 0; m.out_off = 0; m.result = 0; m.in_len = len32; m.out_cap = cap32;
-    hipStream_t st = nullptr;
+    dc.launched();
     if (src_len && hipMemcpyAsync(d_in.p, src, src_len, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
     if (hipMemcpyAsync(d_meta.p, &m, sizeof m, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
     auto *dm = d_meta.as<uint8_t>();
@@ -85,12 +84,8 @@ int64_t run_single(Op op, const uint8_t *src, size_t src_len, uint8_t *dst, size
         rc = zlz4_launch_compress_fast(st, d_in.as<uint8_t>(), p_in_off, p_in_len, d_out.as<uint8_t>(), p_out_off,
                                        p_out_cap, p_res, 1, len32, accel);
     } else if (op == Op::Hc) {
-        const size_t ws = zlz4_hc_workspace_bytes(1, len32);
-        DevBuf d_ws(ws);
-        if (!d_ws.p) return ZLZ4_ERR_ALLOCATION_FAILED;
         rc = zlz4_launch_compress_hc(st, d_in.as<uint8_t>(), p_in_off, p_in_len, d_out.as<uint8_t>(), p_out_off,
                                      p_out_cap, p_res, 1, len32, level, d_ws.p, ws);
-        if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = ZLZ4_ERR_DEVICE;   // d_ws dies at scope end
     } else {
         rc = zlz4_launch_decompress_safe(st, d_in.as<uint8_t>(), p_in_off, p_in_len, d_out.as<uint8_t>(), p_out_off,
                                          p_out_cap, p_res, 1);
@@ -98,7 +93,7 @@ int64_t run_single(Op op, const uint8_t *src, size_t src_len, uint8_t *dst, size
     if (rc != 0) return rc;
     int64_t result = 0;
     if (hipMemcpyAsync(&result, p_res, sizeof result, hipMemcpyDeviceToHost, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
-    if (hipStreamSynchronize(st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    if (!dc.sync()) return ZLZ4_ERR_DEVICE;
     if (result > 0) {
         if ((uint64_t)result > dst_cap) return ZLZ4_ERR_DEVICE;   // cannot happen; never overrun the caller
         if (hipMemcpy(dst, d_out.p, (size_t)result, hipMemcpyDeviceToHost) != hipSuccess) return ZLZ4_ERR_DEVICE;
@@ -220,6 +215,23 @@ int64_t zlz4_decompress_safe_partial(const uint8_t *src, size_t n, uint8_t *dst,
 }
 
 size_t zlz4_sizeof_state(void) { return 4096 * sizeof(uint32_t); }  // src/lz4.zig:524-526, :263-265
+
+// src/lz4hc.zig:1492-1494: @sizeOf(Context) -- hashTable 32768 x u32 + chainTable 65536 x u16 (:391-393) + the scalars
+size_t zlz4_sizeof_state_hc(void) { return 32768u * 4u + 65536u * 2u + 3u * 8u + 3u * 4u + 2u + 1u + 1u + 8u; }
+
+// src/lz4hc.zig:1457-1489.  Differences from compressHC: no `< 2 -> 9` clamp (level < 1 -> 9, level 1 takes the
+// table's row 1 = lz4mid, :72-97), dst.len == 0 is checked here (:1461).
+int64_t zlz4_compress_hc_ext_state(void *state, size_t state_len, const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                                   int32_t level) {
+    if (!state || state_len < zlz4_sizeof_state_hc()) return ZLZ4_ERR_INVALID_STATE;
+    if (n > ZLZ4_MAX_INPUT_SIZE) return ZLZ4_ERR_INPUT_TOO_LARGE;   // :1459
+    if (n == 0) return 0;                                           // :1460
+    if (cap == 0) return ZLZ4_ERR_OUTPUT_TOO_SMALL;                 // :1461
+    if (level < 1) level = ZLZ4HC_CLEVEL_DEFAULT;                   // :1464-1466
+    if (level > ZLZ4HC_CLEVEL_MAX) level = ZLZ4HC_CLEVEL_MAX;
+    if (level == 1) level = 2;                                      // clevelTable[1] == clevelTable[2] (:73-75)
+    return run_single(Op::Hc, src, n, dst, cap, 0, level);
+}
 
 int64_t zlz4_compress_fast_ext_state(void *state, size_t state_len, const uint8_t *src, size_t n, uint8_t *dst,
                                      size_t cap, uint32_t accel) {

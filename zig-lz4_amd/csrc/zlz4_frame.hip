@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "zlz4_device.hpp"
+#include "zlz4_host.hpp"
 
 extern "C" int zlz4_launch_decompress_safe(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
                                            const uint64_t *, const uint32_t *, int64_t *, uint32_t);
@@ -37,6 +38,42 @@ extern "C" int zlz4_launch_compress_hc(hipStream_t, const uint8_t *, const uint6
                                        const uint64_t *, const uint32_t *, int64_t *, uint32_t, uint32_t, int32_t,
                                        void *, size_t);
 extern "C" size_t zlz4_hc_workspace_bytes(uint32_t nblocks, uint32_t max_in_len);
+
+// ------------------------------------------------------------------ device buffers (zlz4_host.hpp)
+namespace {
+struct ParkedBuf { void *p; size_t n; int dev; };
+std::mutex g_park_mutex;
+std::vector<ParkedBuf> g_parked;
+size_t g_parked_bytes = 0;
+constexpr size_t kMaxParked = 12;
+constexpr size_t kMaxParkedBytes = 8ull << 30;   // ~3 % of the HBM: one configs[4] slot arena (4 GiB) and its tables
+}  // namespace
+
+namespace zlz4host {
+void *cache_take(size_t &n, int dev) {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    size_t best = g_parked.size();
+    for (size_t i = 0; i < g_parked.size(); i++)     // smallest parked buffer that fits and is not wastefully large
+        if (g_parked[i].dev == dev && g_parked[i].n >= n && g_parked[i].n / 2 <= n + (1u << 20) &&
+            (best == g_parked.size() || g_parked[i].n < g_parked[best].n))
+            best = i;
+    if (best == g_parked.size()) return nullptr;
+    void *p = g_parked[best].p;
+    n = g_parked[best].n;
+    g_parked_bytes -= n;
+    g_parked.erase(g_parked.begin() + (long)best);
+    return p;
+}
+bool cache_give(void *p, size_t n, int dev) {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    if (g_parked.size() >= kMaxParked || g_parked_bytes + n > kMaxParkedBytes) return false;
+    g_parked.push_back({p, n, dev});
+    g_parked_bytes += n;
+    return true;
+}
+}  // namespace zlz4host
+using zlz4host::DevBuf;
+typedef zlz4host::DeviceCall FrameCall;
 
 namespace {
 
@@ -147,73 +184,6 @@ __host__ __device__ inline ParsedHeader parse_header(const uint8_t *src, size_t 
     r.flg = flg;
     return r;
 }
-
-// ------------------------------------------------------------------ device buffers
-// Scratch memory of the frame calls (block slots, descriptors, plans).  hipMalloc / hipFree of a multi-GiB slot arena
-// cost milliseconds and hipFree synchronises the device, so freed buffers are parked in a small per-process cache
-// and handed out again.  A buffer may only be parked once the work that uses it has finished: every DevBuf belongs to
-// a FrameCall, and the first DevBuf that dies while the call's stream may still be busy (an early error return after
-// kernels were enqueued) synchronises the stream first.  The cache is bounded by count AND by bytes;
-// zlz4_release_device_cache() gives the memory back.
-namespace {
-struct ParkedBuf { void *p; size_t n; int dev; };
-std::mutex g_park_mutex;
-std::vector<ParkedBuf> g_parked;
-size_t g_parked_bytes = 0;
-constexpr size_t kMaxParked = 12;
-constexpr size_t kMaxParkedBytes = 8ull << 30;   // ~3 % of the HBM: one configs[4] slot arena (4 GiB) and its tables
-}  // namespace
-
-struct FrameCall {
-    hipStream_t st;
-    bool idle = true;                 // false between the first launch and the stream synchronisation that follows it
-    explicit FrameCall(hipStream_t s) : st(s) {}
-    void launched() { idle = false; }
-    bool sync() { idle = true; return hipStreamSynchronize(st) == hipSuccess; }
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t n = 0;
-    int dev = 0;
-    FrameCall *call = nullptr;
-    explicit DevBuf(size_t want, FrameCall *fc = nullptr) : call(fc) {
-        n = want ? want : 1;
-        if (hipGetDevice(&dev) != hipSuccess) return;
-        {
-            std::lock_guard<std::mutex> lock(g_park_mutex);
-            size_t best = g_parked.size();
-            for (size_t i = 0; i < g_parked.size(); i++)     // smallest parked buffer that fits and is not wastefully large
-                if (g_parked[i].dev == dev && g_parked[i].n >= n && g_parked[i].n / 2 <= n + (1u << 20) &&
-                    (best == g_parked.size() || g_parked[i].n < g_parked[best].n))
-                    best = i;
-            if (best != g_parked.size()) {
-                p = g_parked[best].p;
-                n = g_parked[best].n;
-                g_parked_bytes -= n;
-                g_parked.erase(g_parked.begin() + (long)best);
-                return;
-            }
-        }
-        if (hipMalloc(&p, n) != hipSuccess) p = nullptr;
-    }
-    ~DevBuf() {
-        if (!p) return;
-        if (call && !call->idle) (void)call->sync();         // error exit with work in flight: wait before anyone reuses p
-        {
-            std::lock_guard<std::mutex> lock(g_park_mutex);
-            if (g_parked.size() < kMaxParked && g_parked_bytes + n <= kMaxParkedBytes) {
-                g_parked.push_back({p, n, dev});
-                g_parked_bytes += n;
-                return;
-            }
-        }
-        (void)hipFree(p);
-    }
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    template <typename T> T *as() const { return static_cast<T *>(p); }
-};
 
 extern "C" void zlz4_release_device_cache(void) {
     std::vector<ParkedBuf> take;

@@ -18,6 +18,14 @@ extern "c" fn zlz4_decompress_safe_partial(src: [*]const u8, src_len: usize, dst
 extern "c" fn zlz4_sizeof_state() usize;
 extern "c" fn zlz4_compress_fast_ext_state(state: [*]u8, state_len: usize, src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, acceleration: u32) i64;
 extern "c" fn zlz4_compress_dest_size(src: [*]const u8, dst: [*]u8, dst_cap: usize, src_size: *usize) i64;
+extern "c" fn zlz4_sizeof_state_hc() usize;
+extern "c" fn zlz4_compress_hc_ext_state(state: [*]u8, state_len: usize, src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, level: i32) i64;
+
+// the data-parallel hot path: device pointers, one wavefront (HC: one workgroup) per block, results per block
+extern "c" fn zlz4_batch_compress_fast(stream: ?*anyopaque, d_in: [*]const u8, d_in_off: [*]const u64, d_in_len: [*]const u32, d_out: [*]u8, d_out_off: [*]const u64, d_out_cap: [*]const u32, d_result: [*]i64, nblocks: u32, max_in_len: u32, acceleration: u32) i32;
+extern "c" fn zlz4_batch_decompress_safe(stream: ?*anyopaque, d_in: [*]const u8, d_in_off: [*]const u64, d_in_len: [*]const u32, d_out: [*]u8, d_out_off: [*]const u64, d_out_cap: [*]const u32, d_result: [*]i64, nblocks: u32) i32;
+extern "c" fn zlz4_batch_compress_hc_workspace(nblocks: u32, max_in_len: u32) usize;
+extern "c" fn zlz4_batch_compress_hc(stream: ?*anyopaque, d_in: [*]const u8, d_in_off: [*]const u64, d_in_len: [*]const u32, d_out: [*]u8, d_out_off: [*]const u64, d_out_cap: [*]const u32, d_result: [*]i64, nblocks: u32, max_in_len: u32, level: i32, d_workspace: ?*anyopaque, workspace_bytes: usize) i32;
 
 pub const CPrefs = extern struct {
     block_size_id: u32 = 0,
@@ -32,6 +40,10 @@ extern "c" fn zlz4f_compress_frame_bound(src_size: usize, prefs: ?*const CPrefs)
 extern "c" fn zlz4f_compress_frame(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize, prefs: ?*const CPrefs) i64;
 extern "c" fn zlz4f_decompress_frame(src: [*]const u8, src_len: usize, dst: [*]u8, dst_cap: usize) i64;
 extern "c" fn zlz4f_header_size(src: [*]const u8, src_len: usize) i64;
+extern "c" fn zlz4f_compress_frame_device(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: ?*const CPrefs) i64;
+extern "c" fn zlz4f_decompress_frame_device(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize) i64;
+extern "c" fn zlz4f_compress_frame_segment_device(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: ?*const CPrefs, segment_flags: u32) i64;
+extern "c" fn zlz4f_decompress_frame_segment_device(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: ?*const CPrefs, segment_flags: u32) i64;
 
 // ---- constants (reference src/lz4.zig:12-25, src/lz4hc.zig:28-31) ----
 pub const MINMATCH = 4;
@@ -98,6 +110,76 @@ pub fn compressDestSize(src: []const u8, dst: []u8, srcSizePtr: *usize) Error!us
 pub fn compressHC(src: []const u8, dst: []u8, compressionLevel: i32) Error!usize {
     return mapBlock(zlz4_compress_hc(src.ptr, src.len, dst.ptr, dst.len, compressionLevel));
 }
+/// reference src/lz4hc.zig:1492-1494
+pub fn sizeofStateHC() usize {
+    return zlz4_sizeof_state_hc();
+}
+/// reference src/lz4hc.zig:1457-1489.  The reference takes `*Context`; its tables live on the device here, so the
+/// context is passed as the bytes it occupies (a fresh `Context.init()`, as compressHC itself uses, :1450).
+pub fn compressHCExtState(ctx: []u8, src: []const u8, dst: []u8, compressionLevel: i32) Error!usize {
+    return mapBlock(zlz4_compress_hc_ext_state(ctx.ptr, ctx.len, src.ptr, src.len, dst.ptr, dst.len, compressionLevel));
+}
+
+/// `@import("lz4").lz4.compressDefault(...)` and `.lz4hc.compressHC(...)` keep working (reference src/root.zig:3-5)
+const root = @This();
+pub const lz4 = struct {
+    pub const Error = root.Error;
+    pub const MINMATCH = 4;
+    pub const LZ4_MAX_INPUT_SIZE = 0x7E000000;
+    pub const LZ4_DISTANCE_MAX = 65535;
+    pub const compressBound = root.compressBound;
+    pub const compressDefault = root.compressDefault;
+    pub const compressFast = root.compressFast;
+    pub const compressDestSize = root.compressDestSize;
+    pub const decompressSafe = root.decompressSafe;
+    pub const decompressSafePartial = root.decompressSafePartial;
+    pub const sizeofState = root.sizeofState;
+    pub const compressFastExtState = root.compressFastExtState;
+};
+pub const lz4hc = struct {
+    pub const LZ4HC_CLEVEL_MIN = 2;
+    pub const LZ4HC_CLEVEL_DEFAULT = 9;
+    pub const LZ4HC_CLEVEL_MAX = 12;
+    pub const compressHC = root.compressHC;
+    pub const compressHCExtState = root.compressHCExtState;
+    pub const sizeofStateHC = root.sizeofStateHC;
+};
+
+/// The hot path itself (no counterpart in the reference, whose calls take one block): many independent blocks per
+/// call, all pointers DEVICE pointers (`[*]` = raw device address), asynchronous on `stream` (a hipStream_t, null =
+/// default stream).  `descs` is the slice-of-slices view a Zig caller has, flattened into the four descriptor arrays
+/// the C ABI takes; they live in device memory like the payload.
+pub const device = struct {
+    pub const Blocks = struct {
+        in: [*]const u8, // input arena
+        in_off: [*]const u64, // per block: offset into `in`
+        in_len: [*]const u32, // per block: bytes
+        out: [*]u8, // output arena
+        out_off: [*]const u64, // per block: offset into `out`
+        out_cap: [*]const u32, // per block: capacity
+        result: [*]i64, // per block: bytes written or -(lz4.Error index)
+        nblocks: u32,
+    };
+    fn mapLaunch(rc: i32) Error!void {
+        if (rc == 0) return;
+        _ = try mapBlock(rc);
+    }
+    /// batch form of compressFast (src/lz4.zig:292-447); every in_len[i] <= max_in_len
+    pub fn compressFastBatch(stream: ?*anyopaque, b: Blocks, max_in_len: u32, acceleration: u32) Error!void {
+        return mapLaunch(zlz4_batch_compress_fast(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks, max_in_len, acceleration));
+    }
+    /// batch form of decompressSafe (src/lz4.zig:257-259)
+    pub fn decompressSafeBatch(stream: ?*anyopaque, b: Blocks) Error!void {
+        return mapLaunch(zlz4_batch_decompress_safe(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks));
+    }
+    pub fn compressHCWorkspace(nblocks: u32, max_in_len: u32) usize {
+        return zlz4_batch_compress_hc_workspace(nblocks, max_in_len);
+    }
+    /// batch form of compressHC (src/lz4hc.zig:1440-1453); `workspace` = device memory of compressHCWorkspace() bytes
+    pub fn compressHCBatch(stream: ?*anyopaque, b: Blocks, max_in_len: u32, level: i32, workspace: ?*anyopaque, workspace_bytes: usize) Error!void {
+        return mapLaunch(zlz4_batch_compress_hc(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks, max_in_len, level, workspace, workspace_bytes));
+    }
+};
 
 /// Mirror of the `lz4f` namespace (reference src/lz4f.zig); enum/struct shapes as in :64-122.
 pub const lz4f = struct {
@@ -165,5 +247,25 @@ pub const lz4f = struct {
     }
     pub fn headerSize(src: []const u8) FrameError!usize {
         return mapFrame(zlz4f_header_size(src.ptr, src.len));
+    }
+
+    /// Device-resident frames (BASELINE configs[4]): `d_src` / `d_dst` are device pointers.
+    pub const SEG_FIRST: u32 = 1;
+    pub const SEG_LAST: u32 = 2;
+    pub fn compressFrameDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: ?Preferences) FrameError!usize {
+        if (prefs) |p| { const c = toC(p); return mapFrame(zlz4f_compress_frame_device(stream, d_src, src_len, d_dst, dst_cap, &c)); }
+        return mapFrame(zlz4f_compress_frame_device(stream, d_src, src_len, d_dst, dst_cap, null));
+    }
+    pub fn decompressFrameDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize) FrameError!usize {
+        return mapFrame(zlz4f_decompress_frame_device(stream, d_src, src_len, d_dst, dst_cap));
+    }
+    /// one rank's block segment of a frame spread over several GPUs (include/zlz4_amd.h)
+    pub fn compressFrameSegmentDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: Preferences, segment_flags: u32) FrameError!usize {
+        const c = toC(prefs);
+        return mapFrame(zlz4f_compress_frame_segment_device(stream, d_src, src_len, d_dst, dst_cap, &c, segment_flags));
+    }
+    pub fn decompressFrameSegmentDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: Preferences, segment_flags: u32) FrameError!usize {
+        const c = toC(prefs);
+        return mapFrame(zlz4f_decompress_frame_segment_device(stream, d_src, src_len, d_dst, dst_cap, &c, segment_flags));
     }
 };
