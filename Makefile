@@ -10,17 +10,21 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 
 all: $(LIB) oracle
 
-$(LIB): $(HIPSRC) $(CSRC)/zlz4_device.hpp include/zlz4_amd.h
+$(LIB): $(HIPSRC) $(CSRC)/zlz4_device.hpp $(CSRC)/zlz4_host.hpp include/zlz4_amd.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)
 
 # diagnostic build: per-phase cycle stamps inside the compress kernel (never shipped / never benchmarked)
-stamps: $(HIPSRC) $(CSRC)/zlz4_device.hpp include/zlz4_amd.h
+stamps: $(HIPSRC) $(CSRC)/zlz4_device.hpp $(CSRC)/zlz4_host.hpp include/zlz4_amd.h
 	$(HIPCC) $(HIPFLAGS) -DZLZ4_STAMPS -shared -o $(PKG)/libzlz4_amd_stamps.so $(HIPSRC)
 
 oracle:
 	$(MAKE) -C oracle
 
+# audit of the decoder's hand-issued loads (see tools/check_decoder_asm.py); run after any toolchain / flag change
+check-asm:
+	python3 tools/check_decoder_asm.py
+
 clean:
 	rm -f $(LIB)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean stamps
+.PHONY: all oracle clean stamps check-asm

@@ -103,7 +103,8 @@ def text_bytes(n, seed, phrase_prob=0.72):
         _TXT = _text_tables()
     mat, lens, wcdf, plen, pw, pcdf = _TXT
     out = np.empty(n, dtype=np.uint8)
-    filled, ctr, chunk = 0, 0, 1 << 18
+    # (counter-based stream: the bytes do not depend on the chunk size; small requests use small chunks)
+    filled, ctr, chunk = 0, 0, min(1 << 18, max(256, n // 8 + 64))
     while filled < n:
         r = u64_stream(seed ^ 0x7E47, chunk * 2, start=ctr).reshape(chunk, 2)
         ctr += chunk * 2
@@ -145,7 +146,7 @@ def reptext_bytes(n, seed):
         _REP = (mat, lens, _zipf_cdf(_RV, 1.0, 1.5))
     mat, lens, cdf = _REP
     out = np.empty(n, dtype=np.uint8)
-    filled, ctr, chunk = 0, 0, 1 << 20
+    filled, ctr, chunk = 0, 0, min(1 << 20, max(256, n // 4 + 64))
     while filled < n:
         r = u64_stream(seed ^ 0x7E47, chunk, start=ctr)
         ctr += chunk

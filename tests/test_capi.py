@@ -93,3 +93,16 @@ def test_cpp_host_mirror_compiles_links_and_runs(zl, tmp_path):
                            "-L", libdir, "-lzlz4_amd", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_decoder_hand_issued_loads_are_not_touched_before_their_wait():
+    """tools/check_decoder_asm.py: the decoder's asm window prefetch must not be read, copied or spilled by compiler code
+    before the asm s_waitcnt that covers it (re-run after any toolchain change)."""
+    import shutil
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_decoder_asm.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -44,6 +44,13 @@ def test_hip_matches_appendix_b_kats(zl, gpu):
             assert hashlib.sha256(out).hexdigest() == v["sha256"]
 
 
+def test_hip_matches_round2_kats(zl, gpu):
+    """kat_round2.json: level 2, levels 10-12, acceleration 7, blocks > 64 KiB, a checksummed frame."""
+    from test_oracle import _check_round2, _round2_fn
+    kat = json.load(open(os.path.join(HERE, "golden", "kat_round2.json")))
+    _check_round2(kat, lambda fn: _round2_fn(zl.compressFast, zl.compressHC, zl.lz4f.compressFrame, zl.Prefs, fn))
+
+
 def _roundtrip(zl, dev, dist, nblocks, block, hc_level=None):
     import bench
     inp = bench.make_device_blocks(dist, nblocks, block, dev, seed=77)

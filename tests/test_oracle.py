@@ -27,7 +27,46 @@ def _kat_input(spec):
         return b"".join(_kat_input(s) for s in spec["concat"])
     if spec.get("special") == "S1":
         return cases.kat_inputs()["S1"]
+    if "gen" in spec:
+        kind, n, seed = spec["gen"]
+        return bytes(dg.GENERATORS[kind](n, seed))
     raise ValueError(spec)
+
+
+def _round2_fn(mod_fast, mod_hc, mod_frame, prefs_cls, fn):
+    """kat_round2.json function names -> a callable on bytes."""
+    if fn == "compressDefault":
+        return lambda b: mod_fast(b, 1)
+    if fn.startswith("compressFast"):
+        return lambda b, a=int(fn[len("compressFast"):]): mod_fast(b, a)
+    if fn.startswith("compressHC"):
+        return lambda b, l=int(fn[len("compressHC"):]): mod_hc(b, l)
+    if fn == "compressFrameChecksums":
+        def frame(b):
+            p = prefs_cls(); p.block_size_id = 4; p.block_mode = 1; p.block_checksum = 1; p.content_checksum = 1
+            return mod_frame(b, p)
+        return frame
+    raise ValueError(fn)
+
+
+def _check_round2(kat, call):
+    for v in kat["vectors"]:
+        data = _kat_input(kat["inputs"][v["input"]])
+        assert hashlib.sha256(data).hexdigest() == v["in_sha256"], v["input"]
+        out = call(v["fn"])(data)
+        assert len(out) == v["len"], (v["input"], v["fn"], len(out))
+        if "hex" in v:
+            assert out.hex() == v["hex"], (v["input"], v["fn"])
+        else:
+            assert hashlib.sha256(out).hexdigest() == v["sha256"], (v["input"], v["fn"])
+
+
+def test_round2_known_answers(oracle):
+    """Level 2, levels 10-12, acceleration 7, blocks > 64 KiB, a checksummed frame: three hand traces and the vectors on
+    which the independent Python restatement and this oracle agree (tests/golden/make_kat_round2.py)."""
+    kat = json.load(open(os.path.join(HERE, "golden", "kat_round2.json")))
+    assert sum(v["provenance"] == "hand" for v in kat["vectors"]) >= 3
+    _check_round2(kat, lambda fn: _round2_fn(oracle.compress_fast, oracle.compress_hc, oracle.compress_frame, oracle.Prefs, fn))
 
 
 def test_appendix_b_known_answers(oracle):
@@ -74,6 +113,18 @@ def test_reference_inequalities(oracle):
         for name, b in cases.reference_test_inputs():
             if len(b) <= 100000:
                 assert oracle.decompress_safe(oracle.compress_hc(b, lvl), len(b)) == b, (name, lvl)
+    # level 10 round trips the reference itself asserts: "ABCD" x 500 at every level 2..12 (src/test_lz4hc.zig:151-186) and
+    # the 500-byte multi-pattern buffer at 10 (:375-433, with size10 <= size9 etc.) -- the early-encode defect of lz4opt
+    #  must not show on them
+    abcd500 = b"ABCD" * 500
+    for lvl in range(2, 13):
+        assert oracle.decompress_safe(oracle.compress_hc(abcd500, lvl), len(abcd500)) == abcd500, lvl
+    pats = [b"ABCD", b"XYZ", b"PQR", b"123", b"abc"]
+    multi = (b"".join(p_ * 3 for p_ in pats) * 40)[:500]
+    sizes = {l: len(oracle.compress_hc(multi, l)) for l in (9, 10, 11, 12)}
+    assert sizes[10] <= sizes[9] and sizes[11] <= sizes[10] and sizes[12] <= sizes[11]
+    for lvl in (10, 11, 12):
+        assert oracle.decompress_safe(oracle.compress_hc(multi, lvl), len(multi)) == multi, lvl
     assert oracle.compress_default(b"") == b"" and oracle.compress_hc(b"", 9) == b""   # src/test.zig:182, lz4hc.zig:1443
     assert oracle.decompress_safe(b"", 10) == b"" and oracle.decompress_safe(b"\x10A", 0) == b""   # lz4.zig:97-98
 
