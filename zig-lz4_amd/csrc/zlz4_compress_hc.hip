@@ -659,12 +659,34 @@ extern "C" size_t zlz4_hc_opt_workspace_bytes(uint32_t chunk_blocks);
 
 namespace zlz4 {
 
+// A second stream per host thread and device for the emit pass: K3 of one round needs no LDS and is bound by the scalar
+// unit, the search of the next round owns the LDS and leaves half the wave slots empty, so the two share the CUs well.
+struct HcSideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t searched[2] = {nullptr, nullptr}, emitted[2] = {nullptr, nullptr};
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int k = 0; k < 2; k++)
+            if (hipEventCreateWithFlags(&searched[k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&emitted[k], hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+};
+static HcSideStream *hc_side_stream() {
+    static thread_local HcSideStream per_device[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    return per_device[dev].init() ? &per_device[dev] : nullptr;
+}
+
 // K1 + K2 (+ K3 for the greedy levels, or the price-based parse for levels 10-12) in rounds of `chunk` blocks
-// (A per-wavefront work-queue form of K2 -- a lane that finishes its chain takes the next unassigned position, first
-//  and chain steps sharing the same two load instructions -- raises the share of busy lanes from 23 % to ~90 % and was
-//  bit-exact, but ran 2.3x SLOWER on MI355X (938 vs 414 ms on configs[3]): neighbouring positions walk neighbouring
-//  chains, so the lock-step kernel's 64 gathers of a trip fall into a few cache lines, while the queue's lanes drift
-//  apart and every gather becomes a random access.  Measured twice in round 1; do not try a third time.)
+// (A per-wavefront work-queue form of the search-every-position K2 -- a lane that finishes its chain takes the next
+//  unassigned position -- was bit-exact but ran 2.3x SLOWER in round 1: neighbouring positions walk neighbouring chains, so
+//  the lock-step kernel's 64 gathers of a trip fall into a few cache lines, while the queue's lanes drift apart.  With
+//  the links in LDS and only the parse's positions searched, k_hc_seg_search is exactly such a queue and wins.)
 template <typename T, typename R>
 int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                       uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, int64_t *d_result,
@@ -679,38 +701,62 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     if (kHcTableSize * sizeof(T) > 65536u)   // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * sizeof(T)));
+    static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
+    const bool seg_search = sizeof(T) == 2 && !optimal && !legacy_search;
+    if constexpr (sizeof(T) == 2) {
+        if (seg_search) {
+            // parse-aware search (k_hc_seg_search).  Rounds of half a chunk, results in the two halves of the result
+            // area in turn: K3 of round r runs on the side stream while K1 / K2s of round r + 1 run on `stream`.
+            static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
+            static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
+            static const bool no_overlap = getenv("ZLZ4_HC_NO_OVERLAP") != nullptr;          // A/B switch for profiles/
+            const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
+            uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;                // ~2 start points per lane
+            if (threads > 1024u) threads = 1024u;
+            if (threads < 64u) threads = 64u;
+            const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
+            const uint32_t lds = lk_bytes + ((np_max + 31u) / 32u + 1u) * 4u;
+            static const int cands = [] { const char *e = getenv("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
+            auto kern = cands == 4 ? &k_hc_seg_search<4> : cands == 2 ? &k_hc_seg_search<2> : &k_hc_seg_search<1>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            HcSideStream *side = (chunk >= 2u && nblocks > chunk / 2u && !no_overlap) ? hc_side_stream() : nullptr;
+            const uint32_t sub = side ? chunk / 2u : chunk;
+            uint32_t round = 0;
+            for (uint32_t b0 = 0; b0 < nblocks; b0 += sub, round++) {
+                const uint32_t nb = nblocks - b0 < sub ? nblocks - b0 : sub;
+                const uint32_t half = side ? (round & 1u) : 0u;
+                uint32_t *res = reinterpret_cast<uint32_t *>(d_res) + (uint64_t)half * sub * stride;
+                if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return -7;   // K3 of round - 2 read this half
+                hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
+                                   d_in_len, d_link, stride, b0, nb, res, max_in_len);
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
+                                   reinterpret_cast<const uint16_t *>(d_link), stride, res, b0, nb, max_attempts, max_in_len,
+                                   lk_bytes, seg_len);
+                hipStream_t emit_on = stream;
+                if (side) {
+                    if (hipEventRecord(side->searched[half], stream) != hipSuccess ||
+                        hipStreamWaitEvent(side->st, side->searched[half], 0) != hipSuccess) return -7;
+                    emit_on = side->st;
+                }
+                hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, emit_on, d_in, d_in_off, d_in_len,
+                                   d_out, d_out_off, d_out_cap, d_result, reinterpret_cast<const R *>(res), stride, b0, nb, max_in_len);
+                if (side && hipEventRecord(side->emitted[half], side->st) != hipSuccess) return -7;
+            }
+            if (side)     // join: everything enqueued here is ordered before whatever the caller enqueues on `stream` next
+                for (uint32_t k = 0; k < 2u && k < round; k++)
+                    if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return -7;
+            return hipGetLastError() == hipSuccess ? 0 : -7;
+        }
+    }
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
-        static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
-        const bool seg_search = sizeof(T) == 2 && !optimal && !legacy_search;
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, b0, nb, seg_search ? reinterpret_cast<uint32_t *>(d_res) : nullptr, max_in_len);
-        if constexpr (sizeof(T) == 2) {
-            if (!optimal && !legacy_search) {
-                // parse-aware search: one lane per 64-position segment, links in LDS
-                static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
-                static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
-                const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
-                uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;            // ~2 start points per lane
-                if (threads > 1024u) threads = 1024u;
-                if (threads < 64u) threads = 64u;
-                const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;    // + padding: the walk reads 3 links ahead
-                const uint32_t lds = lk_bytes + ((np_max + 31u) / 32u + 1u) * 4u;
-                static const int cands = [] { const char *e = getenv("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
-                auto kern = cands == 4 ? &k_hc_seg_search<4> : cands == 2 ? &k_hc_seg_search<2> : &k_hc_seg_search<1>;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
-                                   reinterpret_cast<const uint16_t *>(d_link), stride, reinterpret_cast<uint32_t *>(d_res), b0, nb,
-                                   max_attempts, max_in_len, lk_bytes, seg_len);
-            }
-        }
-        if (sizeof(T) != 2 || optimal || legacy_search) {
-            // every position (the price-based parse of levels 10-12 looks results up everywhere; blocks > 64 KiB)
-            // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
-            //  workgroup finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
-            hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 63u) / 64u, nb), dim3(64), 0, stream, d_in,
-                               d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0, max_in_len);
-        }
+                           d_in_len, d_link, stride, b0, nb, (uint32_t *)nullptr, max_in_len);
+        // every position (the price-based parse of levels 10-12 looks results up everywhere; blocks > 64 KiB)
+        // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
+        //  workgroup finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
+        hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 63u) / 64u, nb), dim3(64), 0, stream, d_in,
+                           d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0, max_in_len);
         if (optimal) {
             const int rc = zlz4_launch_hc_opt_parse(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
                                                     d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len, max_in_len);
