@@ -62,12 +62,23 @@ template <> struct Links<uint32_t> {
 // number of positions that can be searched or inserted: p in [0, n-12]  (:1009 `ip <= mflimit`)
 __device__ __forceinline__ uint32_t n_positions(uint32_t n) { return n < kMfLimit + 1u ? 0u : n - kMfLimit + 1u; }
 
+// insertHC for every position, 256 positions per step.  What the reference does one position at a time --
+//     prev = hashTable[h]; chainTable[idx] = idx - prev; hashTable[h] = idx          (:499-505)
+// -- is ONE LDS instruction per 64 positions here: atomic max with return.  Positions grow with the lane index, so if the
+// LDS unit serves the lanes of an instruction that hit the same slot in ascending lane order, every lane gets back the
+// largest smaller position with its hash (or the value from before the step) = prev, and the slot ends up holding the
+// last one.  That order is not promised by the ISA, so it is checked, not assumed: a lane served before a lower lane of
+// its group leaves a value >= that lane's position in the slot, i.e. some lane reads old >= q (every pre-step value is
+// smaller than every position of the step).  `old < q` on all lanes therefore PROVES the ascending order; otherwise the
+// group is resolved by ballot (prev of a member = the nearest lower member, else the smallest value anyone in the group
+// read, which is the pre-step value).  The 32768-entry table is 32-bit for every block size (LDS atomics are): 128 KiB,
+// one wavefront and one block per CU; k_hc_parse_emit of the previous round fills the rest of the machine.
 template <typename T>
 __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict__ d_in,
                                                         const uint64_t *__restrict__ d_in_off,
                                                         const uint32_t *__restrict__ d_in_len, T *__restrict__ d_link,
                                                         uint64_t link_stride, uint32_t blk0, uint32_t nblocks,
-                                                        uint32_t *__restrict__ d_zero_res, uint32_t max_in_len) {
+                                                        uint32_t max_in_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -77,50 +88,71 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
     if (n > max_in_len) return;                         // the workspace stride comes from max_in_len; K3 reports it
     const uint32_t np = n_positions(n);
     T *link = d_link + (uint64_t)b * link_stride;
-    uint32_t *zero_res = d_zero_res ? d_zero_res + (uint64_t)b * link_stride : nullptr;   // K2s stores matches only
-    typedef __attribute__((address_space(3))) volatile T lds_entry;   // (AS3-typed: ds_read / ds_write, not FLAT)
-    lds_entry *table = (lds_entry *)lds_raw;
+    typedef __attribute__((address_space(3))) uint32_t lds_slot;
+    typedef __attribute__((address_space(3))) T lds_link;
+    lds_slot *table = (lds_slot *)lds_raw;
+    // links are staged in LDS and written out 4096 at a time with 16-byte stores: a global store per step would sit in
+    // the same in-order queue as the prefetch loads and make every step wait for HBM writes
+    constexpr uint32_t kStage = 4096;
+    lds_link *stage = (lds_link *)(lds_raw + kHcTableSize * 4u);
     {
         u32x4 z = {0, 0, 0, 0};
         u32x4 *t4 = reinterpret_cast<u32x4 *>(lds_raw);
-        for (uint32_t k = lane; k < kHcTableSize * sizeof(T) / 16u; k += 64u) t4[k] = z;   // Context.init :405-419
+        for (uint32_t k = lane; k < kHcTableSize * 4u / 16u; k += 64u) t4[k] = z;   // Context.init :405-419
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
-    uint32_t seq_next = lane < np ? ld32(src + lane) : 0u;
-    for (uint32_t base = 0; base < np; base += 64u) {
-        const uint32_t q = base + lane;
-        const bool active = q < np;
-        const uint32_t seq = seq_next;
-        if (q + 64u < np) seq_next = ld32(src + q + 64u);   // next step's bytes are in flight during this step
-        uint32_t h = 0, old = 0, rb = 0;
-        if (active) {
-            h = hash_hc(seq);                           // insertHC :499
-            old = table[h];                             // :500
-            table[h] = (T)q;                            // :505
+    constexpr uint32_t kSub = 4;                        // 64-position groups per step
+    uint32_t seq_next[kSub];
+    for (uint32_t j = 0; j < kSub; j++) seq_next[j] = lane + 64u * j < np ? ld32(src + lane + 64u * j) : 0u;
+    for (uint32_t base = 0; base < np; base += 64u * kSub) {
+        uint32_t seq[kSub], old[kSub];
+        for (uint32_t j = 0; j < kSub; j++) seq[j] = seq_next[j];
+        for (uint32_t j = 0; j < kSub; j++) {           // next step's bytes are in flight during this step
+            const uint32_t qn = base + 64u * (kSub + j) + lane;
+            if (qn < np) seq_next[j] = ld32(src + qn);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (active) rb = table[h];
-        uint64_t losers = ballot(active && rb != (uint32_t)(T)q);
-        uint64_t grp = lane_bit;
-        int32_t pred = -1;
-        while (losers) {                                // one round per duplicate-hash group of this step
-            const uint32_t l = first_lane(losers);
-            const uint32_t hh = rdlane(h, l);
-            const uint64_t same = ballot(active && h == hh);
-            if (active && h == hh) {
-                grp = same;
-                const uint64_t below = same & lanes_below;
-                pred = below ? 63 - (int32_t)__clzll((long long)below) : -1;
+        for (uint32_t j = 0; j < kSub; j++) {           // in position order: LDS operations of a wavefront keep their order
+            const uint32_t q = base + 64u * j + lane;
+            old[j] = 0;
+            if (q < np) old[j] = __hip_atomic_fetch_max(table + hash_hc(seq[j]), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        for (uint32_t j = 0; j < kSub; j++) {
+            const uint32_t q = base + 64u * j + lane;
+            const bool active = q < np;
+            uint32_t prev = old[j];
+            uint64_t viol = ballot(active && prev >= q && q != 0u);   // (position 0 reads the empty slot: prev = 0 is right)
+            if (viol) {
+                // the lanes of some group were not served in ascending order: resolve those groups by ballot
+                const uint32_t h = hash_hc(seq[j]);
+                while (viol) {
+                    const uint32_t hh = rdlane(h, first_lane(viol));
+                    const uint64_t same = ballot(active && h == hh);
+                    uint32_t pre = 0xFFFFFFFFu;           // the pre-step value: the smallest value any member read
+                    for (uint64_t r = same; r; r &= r - 1ull) {
+                        const uint32_t o = rdlane(old[j], first_lane(r));
+                        pre = o < pre ? o : pre;
+                    }
+                    if (active && h == hh) {
+                        const uint64_t below = same & lanes_below;
+                        prev = below ? base + 64u * j + (63u - (uint32_t)__clzll((long long)below)) : pre;
+                    }
+                    viol &= ~same;
+                }
             }
-            losers &= ~same;
+            if (active) stage[q & (kStage - 1u)] = Links<T>::make(q, prev);   // :502-504 (clamp applied on read for T = u32)
         }
-        if (active) {
-            const uint32_t prev = pred >= 0 ? base + (uint32_t)pred : old;
-            link[q] = Links<T>::make(q, prev);          // :502-504 (clamp applied on read for T = u32)
-            if (zero_res) zero_res[q] = 0;
-            if (grp != lane_bit && (grp & ~lanes_below & ~lane_bit) == 0) table[h] = (T)q;   // last of its group
+        const uint32_t done_to = base + 64u * kSub;      // positions below this are staged
+        if ((done_to & (kStage - 1u)) == 0u || done_to >= np) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const uint32_t cb = (done_to - 1u) & ~(kStage - 1u);                // first position of the staged chunk
+            const uint32_t cnt = (done_to < np ? done_to : np) - cb;
+            const uint32_t n16 = (cnt * (uint32_t)sizeof(T) + 15u) >> 4;       // (the link array is padded to 16 entries)
+            const u32x4 *s4 = reinterpret_cast<const u32x4 *>(lds_raw + kHcTableSize * 4u);
+            u32x4 *g4 = reinterpret_cast<u32x4 *>(link + cb);
+            for (uint32_t k = lane; k < n16; k += 64u) g4[k] = s4[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 }
 
@@ -482,11 +514,39 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 const u32x4 b0 = ld128(src + c0 + w);
                 if constexpr (kCands >= 2) b1 = ld128(src + c1 + w);
                 if constexpr (kCands >= 4) { b2 = ld128(src + c2 + w); b3 = ld128(src + c3 + w); }
-                // (a candidate slot that the walk does not reach holds position 0: a harmless load, never looked at;
-                //  after a candidate that raised best_len the rest of the trip is dropped: their window is stale)
-                #define ZLZ4_HC_CAND(C, L, B)                                                                   \
+                // (a candidate slot that the walk does not reach holds position 0: a harmless load, never looked at)
+                const uint32_t fd0 = first_diff16_sel(awin, b0);
+                uint32_t fd1 = 0, fd2 = 0, fd3 = 0;
+                if constexpr (kCands >= 2) fd1 = first_diff16_sel(awin, b1);
+                if constexpr (kCands >= 4) { fd2 = first_diff16_sel(awin, b2); fd3 = first_diff16_sel(awin, b3); }
+                // Fast path: every candidate the walk reaches in this trip is rejected by the window test (the usual
+                // case on a long chain).  Then nothing but the attempt counter and the walk position change, exactly as
+                // :577 / :619-621 would leave them.  att_k = candidate k is attempted (:571), rej_k = it cannot beat
+                // best_len, end_k = the chain ends behind it (:620).
+                auto rejected = [&](uint32_t fd) {
+                    const uint32_t cl = fd < avail ? fd : avail;             // lz4Count stops at iHighLimit
+                    return w != 0u ? fd != 16u : (fd < kMinMatch) | ((fd < 16u) & ((int32_t)cl <= best_len));
+                };
+                const bool end0 = (l0 == 0) | (l0 > c0);
+                bool att1 = false, att2 = false, att3 = false, end1 = true, end2 = true, end3 = true;
+                if constexpr (kCands >= 2) { att1 = !end0 & (c0 - l0 > 0) & (nb > 1); end1 = (l1 == 0) | (l1 > c1); }
+                if constexpr (kCands >= 4) {
+                    att2 = att1 & !end1 & (c1 - l1 > 0) & (nb > 2); end2 = (l2 == 0) | (l2 > c2);
+                    att3 = att2 & !end2 & (c2 - l2 > 0) & (nb > 3); end3 = (l3 == 0) | (l3 > c3);
+                }
+                const bool all_rej = rejected(fd0) & (!att1 | rejected(fd1)) & (!att2 | rejected(fd2)) & (!att3 | rejected(fd3));
+                if (all_rej) {
+                    const uint32_t cl = att3 ? c3 : att2 ? c2 : att1 ? c1 : c0;          // the last candidate attempted
+                    const uint32_t ll = att3 ? l3 : att2 ? l2 : att1 ? l1 : l0;
+                    const bool el = att3 ? end3 : att2 ? end2 : att1 ? end1 : end0;
+                    nb -= 1 + (int32_t)att1 + (int32_t)att2 + (int32_t)att3;              // :577
+                    m = el ? cl : cl - ll;                                                // :620-621
+                    done = !((bool)((int)!el & (int)(nb > 0) & (int)(m > 0)));            // :571
+                } else {
+                // (after a candidate that raised best_len the rest of the trip is dropped: their window is stale)
+                #define ZLZ4_HC_CAND(C, L, FD)                                                                  \
                     if (!done && !in_ext && !changed) {                                                         \
-                        const uint32_t fd = first_diff16_sel(awin, B);                                          \
+                        const uint32_t fd = (FD);                                                               \
                         if (w != 0) {                                                                           \
                             if (fd == 16u) { m = (C); off = 0; in_ext = true; }          /* count it from byte 0 */ \
                             else if (!complete((C), (L), 0u)) done = true;                                      \
@@ -498,10 +558,11 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                             else if (!complete((C), (L), total)) done = true;                                   \
                         }                                                                                       \
                     }
-                ZLZ4_HC_CAND(c0, l0, b0)
-                if constexpr (kCands >= 2) { ZLZ4_HC_CAND(c1, l1, b1) }
-                if constexpr (kCands >= 4) { ZLZ4_HC_CAND(c2, l2, b2) ZLZ4_HC_CAND(c3, l3, b3) }
+                ZLZ4_HC_CAND(c0, l0, fd0)
+                if constexpr (kCands >= 2) { ZLZ4_HC_CAND(c1, l1, fd1) }
+                if constexpr (kCands >= 4) { ZLZ4_HC_CAND(c2, l2, fd2) ZLZ4_HC_CAND(c3, l3, fd3) }
                 #undef ZLZ4_HC_CAND
+                }
             } else {
                 // the candidate at m matched `off` bytes so far: the next 16
                 const uint32_t delta = lk[m];                    // :619 chainTable[matchIndex]
@@ -698,9 +759,9 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     R *d_res = reinterpret_cast<R *>(after_link);
     void *d_opt = after_link + (uint64_t)chunk * stride * sizeof(R);
     const uint32_t np_max = max_in_len < 13u ? 1u : max_in_len - 11u;
-    if (kHcTableSize * sizeof(T) > 65536u)   // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * sizeof(T)));
+    // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * 4u + 4096u * sizeof(T)));
     static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
     const bool seg_search = sizeof(T) == 2 && !optimal && !legacy_search;
     if constexpr (sizeof(T) == 2) {
@@ -727,8 +788,10 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
                 const uint32_t half = side ? (round & 1u) : 0u;
                 uint32_t *res = reinterpret_cast<uint32_t *>(d_res) + (uint64_t)half * sub * stride;
                 if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return -7;   // K3 of round - 2 read this half
-                hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
-                                   d_in_len, d_link, stride, b0, nb, res, max_in_len);
+                // K2s stores matches only: every other position of the parse must read "no match"
+                if (hipMemsetAsync(res, 0, (size_t)nb * stride * sizeof(uint32_t), stream) != hipSuccess) return -7;
+                hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * 4u + 4096u * sizeof(T), stream, d_in, d_in_off,
+                                   d_in_len, d_link, stride, b0, nb, max_in_len);
                 hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
                                    reinterpret_cast<const uint16_t *>(d_link), stride, res, b0, nb, max_attempts, max_in_len,
                                    lk_bytes, seg_len);
@@ -750,8 +813,8 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     }
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
-        hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * sizeof(T), stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, b0, nb, (uint32_t *)nullptr, max_in_len);
+        hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * 4u + 4096u * sizeof(T), stream, d_in, d_in_off,
+                           d_in_len, d_link, stride, b0, nb, max_in_len);
         // every position (the price-based parse of levels 10-12 looks results up everywhere; blocks > 64 KiB)
         // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
         //  workgroup finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
