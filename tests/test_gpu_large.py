@@ -35,10 +35,6 @@ def test_frame_4mib_blocks_bit_exact(zl, oracle, gpu, level, cks):
     for name, b in _frame_inputs():
         if level == 9 and name.startswith("text 9"):
             b = b[: 8 * MIB + 77]                                       # keep the CPU oracle's level-9 time bounded
-        if level == 9 and "zero" in name:
-            # blocks > 64 KiB still take the search-every-position HC kernel, which is quadratic on a 4 MiB run of
-            # one byte (every position counts its match to the end of the block): keep the stored block, drop the run
-            b = b[: 8 * MIB] + bytes(dg.text_bytes(MIB, 24)) + b"tail"
         kw = dict(block_size_id=7, block_mode=1, block_checksum=cks[0], content_checksum=cks[1], compression_level=level)
         want = oracle.compress_frame(b, _prefs(oracle.Prefs, **kw))
         got = zl.lz4f.compressFrame(b, _prefs(zl.Prefs, **kw))
@@ -113,3 +109,19 @@ def test_decompress_batch_output_offsets_cross_2_pow_32(zl, gpu):
         del part
     del out, comp
     torch.cuda.empty_cache()
+
+
+def test_hc_long_runs_are_not_quadratic(zl, oracle, gpu):
+    """Level 9 on blocks that are one long run: every speculative walk of the parse-aware search would count the same
+    huge match; the frontier of the walk from 0 retires them and the count itself is wave-cooperative.  Bit-exact and
+    bounded in time (the search-every-position kernel of round 1 needed minutes for the 4 MiB case)."""
+    import time
+    import gpu_harness as gh
+    items = [bytes(4 << 20), b"\xAB" * (1 << 20) + bytes(dg.text_bytes(3000, 5)), bytes(65536), b"ab" * 40000,
+             bytes(dg.text_bytes(50000, 6)) + bytes(200000)]
+    t0 = time.time()
+    got = gh.compress_hc(zl, items, gpu, 9)
+    dt = time.time() - t0
+    for b, (n, c) in zip(items, got):
+        assert c == oracle.compress_hc(b, 9), len(b)
+    assert dt < 20.0, "level 9 on long runs took %.1f s" % dt

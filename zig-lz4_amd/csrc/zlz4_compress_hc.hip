@@ -25,6 +25,7 @@
 // K2 does redundant work for positions inside matches, but it has 64K-way parallelism per
 // block where the reference has none.
 #include <cstdlib>
+#include <type_traits>
 
 #include "zlz4_device.hpp"
 
@@ -171,6 +172,17 @@ __device__ __forceinline__ uint32_t lz4_count(const uint8_t *src, uint32_t a, ui
 // countPattern (:170-199) for a pattern that passed isRepetitivePattern (all four bytes equal)
 __device__ __forceinline__ uint32_t count_pattern(const uint8_t *src, uint32_t a, uint32_t end, uint32_t pattern) {
     uint32_t c = 0;
+    while (a + 16u <= end) {                            // (16 bytes per round trip: this loop is one lane's serial chain)
+        const u32x4 v = ld128(src + a);
+        const uint32_t x0 = v.x ^ pattern, x1 = v.y ^ pattern, x2 = v.z ^ pattern, x3 = v.w ^ pattern;
+        if (x0 | x1 | x2 | x3) {
+            if (x0) return c + ((uint32_t)__builtin_ctz(x0) >> 3);
+            if (x1) return c + 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+            if (x2) return c + 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+            return c + 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+        }
+        a += 16; c += 16;
+    }
     while (a + 4u <= end) {
         const uint32_t x = ld32(src + a) ^ pattern;
         if (x) return c + ((uint32_t)__builtin_ctz(x) >> 3);
@@ -184,6 +196,11 @@ __device__ __forceinline__ uint32_t count_pattern(const uint8_t *src, uint32_t a
 __device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, uint32_t a, uint32_t pattern) {
     uint32_t c = 0;
     const uint8_t pb = (uint8_t)pattern;
+    while (a >= 16u) {
+        const u32x4 v = ld128(src + a - 16u);
+        if ((v.x ^ pattern) | (v.y ^ pattern) | (v.z ^ pattern) | (v.w ^ pattern)) break;
+        a -= 16; c += 16;
+    }
     while (a >= 4u && ld32(src + a - 4u) == pattern) { a -= 4; c += 4; }
     while (a > 0 && src[a - 1u] == pb) { a--; c++; }
     return c;
@@ -344,15 +361,47 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-template <int kCands>   // candidates of a chain examined per loop trip (1, 2 or 4)
+// Wave-cooperative lz4Count (:234-264) for one long match: bytes equal at a + k / b + k, k >= from, while a + k < limit;
+// 16 bytes per lane and step (1 KiB per step).  All 64 lanes must call it with the same arguments.
+__device__ __forceinline__ uint32_t hc_coop_count(const uint8_t *__restrict__ src, uint32_t a, uint32_t b, uint32_t from,
+                                                  uint32_t limit, uint32_t n, uint32_t lane) {
+    uint32_t k = from;
+    for (;;) {
+        const uint32_t pa = a + k + lane * 16u;
+        uint32_t cmp = 0, d = 0;                          // bytes this lane may compare / equal bytes found
+        if (pa < limit) cmp = limit - pa < 16u ? limit - pa : 16u;
+        if (cmp) {
+            const uint32_t pb = b + k + lane * 16u;
+            if (pa + 16u <= n) { d = first_diff16_sel(ld128(src + pa), ld128(src + pb)); d = d < cmp ? d : cmp; }
+            else while (d < cmp && src[pa + d] == src[pb + d]) d++;
+        }
+        const uint64_t stop = ballot(d < 16u);            // mismatch or limit inside this lane's chunk
+        if (stop) {
+            const uint32_t sl = first_lane(stop);
+            return k + sl * 16u + rdlane(d, sl);
+        }
+        k += 1024u;
+    }
+}
+
+// kLds = true : blocks <= 64 KiB, links = u16 deltas (q - prev) copied into LDS, results u32 (len | off << 16), bitmap in LDS
+// kLds = false: any block size, links = u32 predecessors read from the HBM workspace, results u64 (len | off << 32), bitmap
+//               in the workspace (zeroed by the launcher).  Here the walk also meets the two tests that cannot fire in
+//               a 64 KiB block: candidates further than 65535 bytes end the walk (:573), candidates below
+//               lowestMatchIndex are counted but not compared (:579).
+template <int kCands, bool kLds>   // kCands = candidates of a chain examined per loop trip (1, 2 or 4)
 __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restrict__ d_in,
                                                          const uint64_t *__restrict__ d_in_off,
                                                          const uint32_t *__restrict__ d_in_len,
-                                                         const uint16_t *__restrict__ d_link, uint64_t link_stride,
-                                                         uint32_t *__restrict__ d_res, uint32_t blk0, uint32_t nblocks,
+                                                         const void *__restrict__ d_link_v, uint64_t link_stride,
+                                                         void *__restrict__ d_res_v, uint32_t *__restrict__ d_bitmap,
+                                                         uint64_t bitmap_stride, uint32_t blk0, uint32_t nblocks,
                                                          int32_t max_attempts, uint32_t max_in_len, uint32_t lk_bytes,
                                                          uint32_t seg_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    typedef typename std::conditional<kLds, uint16_t, uint32_t>::type T;
+    typedef typename std::conditional<kLds, uint32_t, uint64_t>::type R;
+    typedef typename std::conditional<kLds, const lds_u16 *, const uint32_t *>::type LinkPtr;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const uint32_t n = d_in_len[blk0 + b];
@@ -360,19 +409,42 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     const uint32_t np = n_positions(n);
     if (np == 0) return;
     const uint8_t *src = d_in + d_in_off[blk0 + b];
-    uint32_t *res = d_res + (uint64_t)b * link_stride;
-    const lds_u16 *lk = (const lds_u16 *)lds_raw;
-    lds_u32 *bm = (lds_u32 *)(lds_raw + lk_bytes);               // visited bitmap, one bit per position
-    const uint32_t bm_words = (np + 31u) >> 5;
-    lds_u32 *next_seg = bm + bm_words;                           // start-point counter
-    {
-        const u32x4 *g4 = reinterpret_cast<const u32x4 *>(d_link + (uint64_t)b * link_stride);
+    R *res = static_cast<R *>(d_res_v) + (uint64_t)b * link_stride;
+    LinkPtr lk;
+    lds_u32 *next_seg;                                           // start-point counter
+    [[maybe_unused]] lds_u32 *bm_l = nullptr;                    // visited bitmap, one bit per position
+    [[maybe_unused]] uint32_t *bm_g = nullptr;
+    if constexpr (kLds) {
+        lk = (const lds_u16 *)lds_raw;
+        bm_l = (lds_u32 *)(lds_raw + lk_bytes);
+        const uint32_t bm_words = (np + 31u) >> 5;
+        next_seg = bm_l + bm_words;                              // [0] start-point counter, [1] frontier of the walk from 0, [2] that walk is over
+        const u32x4 *g4 = reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(d_link_v) + (uint64_t)b * link_stride);
         u32x4 *l4 = reinterpret_cast<u32x4 *>(lds_raw);
         const uint32_t n16 = (np * 2u + 15u) >> 4;
         for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) l4[k] = g4[k];
-        for (uint32_t k = threadIdx.x; k <= bm_words; k += blockDim.x) bm[k] = 0;
+        for (uint32_t k = threadIdx.x; k <= bm_words + 2u; k += blockDim.x) bm_l[k] = 0;
+    } else {
+        lk = static_cast<const uint32_t *>(d_link_v) + (uint64_t)b * link_stride;
+        bm_g = d_bitmap + (uint64_t)b * bitmap_stride;
+        next_seg = (lds_u32 *)lds_raw;
+        if (threadIdx.x < 3u) next_seg[threadIdx.x] = 0;
     }
     __syncthreads();
+    // what a link says: the first candidate of q (0 = none), the distance to the next one (:502-504, :619)
+    auto first_of = [](uint32_t q, uint32_t raw) { return kLds ? q - raw : raw; };
+    auto delta_of = [](uint32_t mm, uint32_t raw) { return Links<T>::delta(mm, (T)raw); };
+    auto mark = [&](uint32_t q) -> bool {                        // true = q was marked already
+        const uint32_t bit = 1u << (q & 31u);
+        uint32_t old;
+        if constexpr (kLds) old = __hip_atomic_fetch_or(bm_l + (q >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else old = __hip_atomic_fetch_or(bm_g + (q >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (old & bit) != 0;
+    };
+    auto pack = [](int32_t len, uint32_t off_) -> R {
+        if constexpr (kLds) return (uint32_t)len | (off_ << 16);
+        else return (uint64_t)(uint32_t)len | ((uint64_t)off_ << 32);
+    };
     const bool pattern_analysis = max_attempts > 128;            // :983
     const uint32_t limit = n - kLastLiterals;                    // iHighLimit = matchlimit :989, :1011
     const uint32_t nseg = (np + seg_len - 1u) / seg_len;
@@ -380,10 +452,13 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 
     bool have = false, exhausted = false, in_chain = false, in_ext = false, fresh = false;
+    bool is_true = false;                                        // this lane runs the walk that started at position 0
+    bool ext_final = false;                                      // `off` already is the candidate's full match length
     u32x4 p16 = {0, 0, 0, 0};                                    // the 16 bytes at pos
     u32x4 aw = p16;                                              // the 16 bytes at pos + aw_off (the compare window)
     uint32_t aw_off = 0;
     uint32_t pos = 0, m = 0, off = 0, avail = 0, best_off = 0;
+    [[maybe_unused]] uint32_t lowest = 0;                        // lowestMatchIndex :553-554 (0 in a 64 KiB block)
     int32_t nb = 0, best_len = (int32_t)kMinMatch - 1;
 #ifdef ZLZ4_STAMPS
     unsigned long long st_trips = 0, st_chain = 0, st_fetch = 0, st_walks = 0, t_assign = 0, t_fetch = 0, t_chain = 0;
@@ -403,11 +478,18 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
             base = rdlane(base, first_lane(want));
             if (!have && !exhausted) {
                 const uint32_t seg = base + (uint32_t)__popcll(want & lanes_below);
-                if (seg < nseg) { pos = seg * seg_len; have = true; in_chain = false; }
+                if (seg < nseg) { pos = seg * seg_len; have = true; in_chain = false; is_true = seg == 0u; }
                 else exhausted = true;
             }
         }
-        if (!ballot(have)) break;
+        // The walk from position 0 IS the parse as long as it has not merged into another walk; everything below its
+        // frontier is settled, so start points and walks below it are dropped.  (Without this a block that begins with
+        // one huge match -- zeros, a constant prefix -- would have every other lane count the same huge match.)
+        const uint32_t fword = __hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t frontier = fword & 0x7FFFFFFFu;           // (bit 31: the walk from 0 is over)
+        if (have && !is_true && pos < frontier) { have = false; in_chain = false; in_ext = false; ext_final = false; }
+        if (have && is_true) __hip_atomic_store(next_seg + 1, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!ballot(have) && !ballot(!exhausted)) break;
         HSTAMP(t_assign, t0);
 #ifdef ZLZ4_STAMPS
         st_trips += 1; st_walks += __popcll(want); st_fetch += __popcll(ballot(have && !in_chain));
@@ -419,28 +501,47 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         //      reach the position that ends the run, and merge there.
         if (have && !in_chain) {
             for (int it = 0; it < 2; ++it) {
-                if (pos >= np) { have = false; break; }
-                const uint32_t l0 = lk[pos], l1 = lk[pos + 1u], l2 = lk[pos + 2u], l3 = lk[pos + 3u];   // (LDS is padded)
-                const uint32_t k = l0 != pos ? 0u : l1 != pos + 1u ? 1u : l2 != pos + 2u ? 2u : l3 != pos + 3u ? 3u : 4u;
+                if (pos >= np) {
+                    if (is_true) {
+                        __hip_atomic_store(next_seg + 1, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(next_seg + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    have = false;
+                    break;
+                }
+                const uint32_t l0 = lk[pos], l1 = lk[pos + 1u], l2 = lk[pos + 2u], l3 = lk[pos + 3u];   // (both arrays are padded)
+                const uint32_t k = first_of(pos, l0) != 0u ? 0u : first_of(pos + 1u, l1) != 0u ? 1u
+                                 : first_of(pos + 2u, l2) != 0u ? 2u : first_of(pos + 3u, l3) != 0u ? 3u : 4u;
                 pos += k;
-                if (pos >= np) { have = false; break; }          // (also ends a run that ran into the garbage past np)
+                if (pos >= np) {                                 // (also ends a run that ran into the garbage past np)
+                    if (is_true) {
+                        __hip_atomic_store(next_seg + 1, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(next_seg + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    have = false;
+                    break;
+                }
                 if (k == 4u) continue;
                 const uint32_t l = k == 0u ? l0 : k == 1u ? l1 : k == 2u ? l2 : l3;
-                const uint32_t bit = 1u << (pos & 31u);
-                const uint32_t old = __hip_atomic_fetch_or(bm + (pos >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (old & bit) { have = false; break; }          // somebody else's walk continues from here
-                m = pos - l;                                     // :563 hashTable[hashPtr(ip)], != 0 here
+                if (mark(pos)) {                                 // somebody else's walk continues from here
+                    if (is_true) __hip_atomic_fetch_or(next_seg + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    have = false;
+                    break;
+                }
+                m = first_of(pos, l);                            // :563 hashTable[hashPtr(ip)], != 0 here
                 best_len = (int32_t)kMinMatch - 1;               // :560
                 best_off = 0;
                 nb = max_attempts;
+                if constexpr (!kLds) lowest = pos < 65536u ? 0u : pos - kMaxDist;
                 if (pos + 16u > n) {
                     // the last <= 4 searchable positions of a block: no room for 16-byte compares
                     const uint32_t pattern = ld32(src + pos);
-                    while (m > 0 && nb > 0) {                    // :571 (m <= pos and pos - m <= 65535 hold for u16 links)
+                    while (m > 0 && nb > 0) {                    // :571
+                        if (!kLds && (m > pos || pos - m > kMaxDist)) break;   // :573
                         nb -= 1;                                 // :577
-                        const uint32_t delta = lk[m];
+                        const uint32_t delta = delta_of(m, lk[m]);
                         int32_t mlt = 0;
-                        if (ld32(src + m) == pattern)            // :586
+                        if ((kLds || m >= lowest) && ld32(src + m) == pattern)   // :579, :586
                             mlt = (int32_t)(kMinMatch + lz4_count(src, pos + kMinMatch, m + kMinMatch, limit));
                         if (mlt > best_len) {                    // :607
                             best_len = mlt;
@@ -451,10 +552,18 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                         m -= delta;                              // :621
                     }
                     if (pattern_analysis)
-                        hc_pattern_step<uint16_t, const lds_u16 *>(src, lk, pos, m, pattern, 0u, limit, best_len, best_off);
+                        hc_pattern_step<T, LinkPtr>(src, lk, pos, m, pattern, lowest, limit, best_len, best_off);
                     const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
-                    if (found) res[pos] = (uint32_t)best_len | (best_off << 16);
+                    if (found) res[pos] = pack(best_len, best_off);
                     pos += found ? (uint32_t)best_len : 1u;      // :1013-1016, :382
+                    continue;
+                }
+                if (!kLds && pos - m > kMaxDist) {               // :573 on the first candidate: the walk ends at once
+                    if (pattern_analysis)
+                        hc_pattern_step<T, LinkPtr>(src, lk, pos, m, ld32(src + pos), lowest, limit, best_len, best_off);
+                    const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
+                    if (found) res[pos] = pack(best_len, best_off);
+                    pos += found ? (uint32_t)best_len : 1u;
                     continue;
                 }
                 avail = limit - pos;                             // lz4Count stops at iHighLimit
@@ -470,8 +579,29 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         st_chain += __popcll(ballot(have && in_chain));
         t0 = HNOW();
 #endif
+        // ---- a candidate that has matched 64 bytes and more is counted by the whole wavefront, 1 KiB per step, lowest
+        //      lane first (lane 0 of wave 0 runs the walk from 0, whose frontier then retires the others)
+        // While the walk from 0 is still on its own, the other walks do not start a long count: most likely its frontier
+        // is about to retire them (a block that is one long run), and if it merges first they go on from where they are.
+        const bool walk0_over = (fword >> 31) != 0u;
+        const bool parked = have && in_chain && in_ext && !ext_final && off >= 64u && !is_true && !walk0_over;
+        {
+            uint64_t longm = ballot(have && in_chain && in_ext && !ext_final && off >= 64u && !parked);
+            while (longm) {
+                const uint32_t L = first_lane(longm);
+                longm &= longm - 1ull;
+                const uint32_t P = rdlane(pos, L);
+                const bool walk0 = rdlane((uint32_t)is_true, L) != 0;
+                if (!walk0 && P < (__hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x7FFFFFFFu)) {
+                    if (lane == L) { have = false; in_chain = false; in_ext = false; }
+                    continue;
+                }
+                const uint32_t total = hc_coop_count(src, P, rdlane(m, L), rdlane(off, L), limit, n, lane);
+                if (lane == L) { off = total; ext_final = true; }
+            }
+        }
         // ---- one round trip of the chain walk :571-622
-        if (have && in_chain) {
+        if (have && in_chain && !parked) {
             // a candidate is done: :577, :586-:621.  `total` = its match length (bytes equal to the ones at pos, not yet
             // clamped), or 0 for a candidate that is known not to beat best_len (the reference counts those in full,
             // :588, but only `mlt > longest` is ever used, :607)
@@ -485,27 +615,27 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 best_off = better ? pos - c : best_off;
                 const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > c);   // :613, :620
                 m = stop ? c : c - delta;                        // :621
-                return (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0));
+                return (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0) & (int)(kLds || pos - m <= kMaxDist));   // :571, :573
             };
             bool done = false;                                   // the search at pos is over
             if (!in_ext) {
-                // up to kCands candidates per trip: the links are chased in LDS first (the walk itself does not depend on
-                // the compares), then the 16-byte loads fly together.  A candidate can only matter if it matches MORE
+                // up to kCands candidates per trip: the links are chased first (the walk itself does not depend on the
+                // compares), then the 16-byte loads fly together.  A candidate can only matter if it matches MORE
                 // than best_len bytes, so what is compared first is the 16-byte window that ends at byte best_len
                 // (bytes 0..15 while best_len < 16): a mismatch there settles it in one load, whatever the candidate's
                 // real length -- at level 9 a frequent 4-gram has 256 candidates that match 20-40 bytes each.
                 const uint32_t w = best_len >= 16 ? (uint32_t)best_len - 15u : 0u;
-                const uint32_t c0 = m, l0 = lk[c0];
+                const uint32_t c0 = m, l0 = delta_of(c0, lk[c0]);                 // l_k = distance to the next candidate
                 uint32_t c1 = 0, l1 = 0, c2 = 0, l2 = 0, c3 = 0, l3 = 0;
                 u32x4 b1 = {0, 0, 0, 0}, b2 = b1, b3 = b1;
                 if constexpr (kCands >= 2) {
                     const bool k1 = !(l0 == 0 || l0 > c0) && c0 - l0 > 0;
-                    c1 = k1 ? c0 - l0 : 0; l1 = lk[c1];
+                    c1 = k1 ? c0 - l0 : 0; l1 = delta_of(c1, lk[c1]);
                     if constexpr (kCands >= 4) {
                         const bool k2 = k1 && !(l1 == 0 || l1 > c1) && c1 - l1 > 0;
-                        c2 = k2 ? c1 - l1 : 0; l2 = lk[c2];
+                        c2 = k2 ? c1 - l1 : 0; l2 = delta_of(c2, lk[c2]);
                         const bool k3 = k2 && !(l2 == 0 || l2 > c2) && c2 - l2 > 0;
-                        c3 = k3 ? c2 - l2 : 0; l3 = lk[c3];
+                        c3 = k3 ? c2 - l2 : 0; l3 = delta_of(c3, lk[c3]);
                     }
                 }
                 if (fresh) { p16 = ld128(src + pos); aw_off = 0; fresh = false; }
@@ -521,33 +651,37 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 if constexpr (kCands >= 4) { fd2 = first_diff16_sel(awin, b2); fd3 = first_diff16_sel(awin, b3); }
                 // Fast path: every candidate the walk reaches in this trip is rejected by the window test (the usual
                 // case on a long chain).  Then nothing but the attempt counter and the walk position change, exactly as
-                // :577 / :619-621 would leave them.  att_k = candidate k is attempted (:571), rej_k = it cannot beat
-                // best_len, end_k = the chain ends behind it (:620).
-                auto rejected = [&](uint32_t fd) {
+                // :577 / :619-621 would leave them.  att_k = candidate k is attempted (:571, :573), rej_k = it cannot
+                // beat best_len (or lies below lowestMatchIndex, :579), end_k = the chain ends behind it (:620).
+                auto rejected = [&](uint32_t c, uint32_t fd) {
                     const uint32_t cl = fd < avail ? fd : avail;             // lz4Count stops at iHighLimit
-                    return w != 0u ? fd != 16u : (fd < kMinMatch) | ((fd < 16u) & ((int32_t)cl <= best_len));
+                    const bool r = w != 0u ? fd != 16u : (fd < kMinMatch) | ((fd < 16u) & ((int32_t)cl <= best_len));
+                    return kLds ? r : (r | (c < lowest));
                 };
+                auto near_enough = [&](uint32_t c) { return kLds || pos - c <= kMaxDist; };
                 const bool end0 = (l0 == 0) | (l0 > c0);
                 bool att1 = false, att2 = false, att3 = false, end1 = true, end2 = true, end3 = true;
-                if constexpr (kCands >= 2) { att1 = !end0 & (c0 - l0 > 0) & (nb > 1); end1 = (l1 == 0) | (l1 > c1); }
+                if constexpr (kCands >= 2) { att1 = !end0 & (c0 - l0 > 0) & (nb > 1) & near_enough(c1); end1 = (l1 == 0) | (l1 > c1); }
                 if constexpr (kCands >= 4) {
-                    att2 = att1 & !end1 & (c1 - l1 > 0) & (nb > 2); end2 = (l2 == 0) | (l2 > c2);
-                    att3 = att2 & !end2 & (c2 - l2 > 0) & (nb > 3); end3 = (l3 == 0) | (l3 > c3);
+                    att2 = att1 & !end1 & (c1 - l1 > 0) & (nb > 2) & near_enough(c2); end2 = (l2 == 0) | (l2 > c2);
+                    att3 = att2 & !end2 & (c2 - l2 > 0) & (nb > 3) & near_enough(c3); end3 = (l3 == 0) | (l3 > c3);
                 }
-                const bool all_rej = rejected(fd0) & (!att1 | rejected(fd1)) & (!att2 | rejected(fd2)) & (!att3 | rejected(fd3));
+                const bool all_rej = rejected(c0, fd0) & (!att1 | rejected(c1, fd1)) & (!att2 | rejected(c2, fd2)) &
+                                     (!att3 | rejected(c3, fd3));
                 if (all_rej) {
                     const uint32_t cl = att3 ? c3 : att2 ? c2 : att1 ? c1 : c0;          // the last candidate attempted
                     const uint32_t ll = att3 ? l3 : att2 ? l2 : att1 ? l1 : l0;
                     const bool el = att3 ? end3 : att2 ? end2 : att1 ? end1 : end0;
                     nb -= 1 + (int32_t)att1 + (int32_t)att2 + (int32_t)att3;              // :577
                     m = el ? cl : cl - ll;                                                // :620-621
-                    done = !((bool)((int)!el & (int)(nb > 0) & (int)(m > 0)));            // :571
+                    done = !((bool)((int)!el & (int)(nb > 0) & (int)(m > 0) & (int)near_enough(m)));   // :571, :573
                 } else {
                 // (after a candidate that raised best_len the rest of the trip is dropped: their window is stale)
                 #define ZLZ4_HC_CAND(C, L, FD)                                                                  \
                     if (!done && !in_ext && !changed) {                                                         \
                         const uint32_t fd = (FD);                                                               \
-                        if (w != 0) {                                                                           \
+                        if (!kLds && (C) < lowest) { if (!complete((C), (L), 0u)) done = true; }    /* :579 */  \
+                        else if (w != 0) {                                                                      \
                             if (fd == 16u) { m = (C); off = 0; in_ext = true; }          /* count it from byte 0 */ \
                             else if (!complete((C), (L), 0u)) done = true;                                      \
                         } else {                                                                                \
@@ -565,24 +699,29 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 }
             } else {
                 // the candidate at m matched `off` bytes so far: the next 16
-                const uint32_t delta = lk[m];                    // :619 chainTable[matchIndex]
-                const u32x4 a16 = ld128(src + pos + off);
-                const u32x4 b16 = ld128(src + m + off);          // m < pos, so m + off + 16 <= n too
-                uint32_t total = off + first_diff16_sel(a16, b16);
-                bool more = total == off + 16u && total < avail;
-                if (more && pos + total + 16u > n) {             // no room for another 16-byte compare: finish by bytes
-                    total += lz4_count(src, pos + total, m + total, limit);
-                    more = false;
+                const uint32_t delta = delta_of(m, lk[m]);       // :619 chainTable[matchIndex]
+                uint32_t total = off;
+                bool more = false;
+                if (!ext_final) {
+                    const u32x4 a16 = ld128(src + pos + off);
+                    const u32x4 b16 = ld128(src + m + off);      // m < pos, so m + off + 16 <= n too
+                    total = off + first_diff16_sel(a16, b16);
+                    more = total == off + 16u && total < avail;
+                    if (more && pos + total + 16u > n) {         // no room for another 16-byte compare: finish by bytes
+                        total += lz4_count(src, pos + total, m + total, limit);
+                        more = false;
+                    }
                 }
+                ext_final = false;
                 if (more) off = total;
                 else { in_ext = false; done = !complete(m, delta, total); }
             }
             if (done) {
                 if (pattern_analysis)
-                    hc_pattern_step<uint16_t, const lds_u16 *>(src, lk, pos, m, p16.x, 0u, limit, best_len, best_off);
+                    hc_pattern_step<T, LinkPtr>(src, lk, pos, m, p16.x, lowest, limit, best_len, best_off);
                 const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
 #ifndef ZLZ4_EXPERIMENT_NOSTORE
-                if (found) res[pos] = (uint32_t)best_len | (best_off << 16);
+                if (found) res[pos] = pack(best_len, best_off);
 #endif
                 pos += found ? (uint32_t)best_len : 1u;          // :1013-1016, :382
                 in_chain = false;
@@ -763,53 +902,55 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * 4u + 4096u * sizeof(T)));
     static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
-    const bool seg_search = sizeof(T) == 2 && !optimal && !legacy_search;
-    if constexpr (sizeof(T) == 2) {
-        if (seg_search) {
-            // parse-aware search (k_hc_seg_search).  Rounds of half a chunk, results in the two halves of the result
-            // area in turn: K3 of round r runs on the side stream while K1 / K2s of round r + 1 run on `stream`.
-            static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
-            static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
-            static const bool no_overlap = getenv("ZLZ4_HC_NO_OVERLAP") != nullptr;          // A/B switch for profiles/
-            const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
-            uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;                // ~2 start points per lane
-            if (threads > 1024u) threads = 1024u;
-            if (threads < 64u) threads = 64u;
-            const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
-            const uint32_t lds = lk_bytes + ((np_max + 31u) / 32u + 1u) * 4u;
-            static const int cands = [] { const char *e = getenv("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
-            auto kern = cands == 4 ? &k_hc_seg_search<4> : cands == 2 ? &k_hc_seg_search<2> : &k_hc_seg_search<1>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            HcSideStream *side = (chunk >= 2u && nblocks > chunk / 2u && !no_overlap) ? hc_side_stream() : nullptr;
-            const uint32_t sub = side ? chunk / 2u : chunk;
-            uint32_t round = 0;
-            for (uint32_t b0 = 0; b0 < nblocks; b0 += sub, round++) {
-                const uint32_t nb = nblocks - b0 < sub ? nblocks - b0 : sub;
-                const uint32_t half = side ? (round & 1u) : 0u;
-                uint32_t *res = reinterpret_cast<uint32_t *>(d_res) + (uint64_t)half * sub * stride;
-                if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return -7;   // K3 of round - 2 read this half
-                // K2s stores matches only: every other position of the parse must read "no match"
-                if (hipMemsetAsync(res, 0, (size_t)nb * stride * sizeof(uint32_t), stream) != hipSuccess) return -7;
-                hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * 4u + 4096u * sizeof(T), stream, d_in, d_in_off,
-                                   d_in_len, d_link, stride, b0, nb, max_in_len);
-                hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
-                                   reinterpret_cast<const uint16_t *>(d_link), stride, res, b0, nb, max_attempts, max_in_len,
-                                   lk_bytes, seg_len);
-                hipStream_t emit_on = stream;
-                if (side) {
-                    if (hipEventRecord(side->searched[half], stream) != hipSuccess ||
-                        hipStreamWaitEvent(side->st, side->searched[half], 0) != hipSuccess) return -7;
-                    emit_on = side->st;
-                }
-                hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, emit_on, d_in, d_in_off, d_in_len,
-                                   d_out, d_out_off, d_out_cap, d_result, reinterpret_cast<const R *>(res), stride, b0, nb, max_in_len);
-                if (side && hipEventRecord(side->emitted[half], side->st) != hipSuccess) return -7;
+    const bool seg_search = !optimal && !legacy_search;
+    if (seg_search) {
+        // parse-aware search (k_hc_seg_search).  Rounds of half a chunk, results in the two halves of the result
+        // area in turn: K3 of round r runs on the side stream while K1 / K2s of round r + 1 run on `stream`.
+        constexpr bool kLds = sizeof(T) == 2;
+        static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
+        static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
+        static const bool no_overlap = getenv("ZLZ4_HC_NO_OVERLAP") != nullptr;          // A/B switch for profiles/
+        const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
+        uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;                // ~2 start points per lane
+        if (threads > 1024u) threads = 1024u;
+        if (threads < 64u) threads = 64u;
+        const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
+        const uint32_t lds = kLds ? lk_bytes + ((np_max + 31u) / 32u + 3u) * 4u : 16u;
+        static const int cands = [] { const char *e = getenv("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
+        auto kern = cands == 4 ? &k_hc_seg_search<4, kLds> : cands == 2 ? &k_hc_seg_search<2, kLds> : &k_hc_seg_search<1, kLds>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const uint64_t bm_stride = (stride + 31u) / 32u + 1u;                // bitmap words per block (HBM links only)
+        uint32_t *d_bitmap = static_cast<uint32_t *>(d_opt);                 // (the area of the price-based parse is idle here)
+        HcSideStream *side = (chunk >= 2u && nblocks > chunk / 2u && !no_overlap) ? hc_side_stream() : nullptr;
+        const uint32_t sub = side ? chunk / 2u : chunk;
+        uint32_t round = 0;
+        for (uint32_t b0 = 0; b0 < nblocks; b0 += sub, round++) {
+            const uint32_t nb = nblocks - b0 < sub ? nblocks - b0 : sub;
+            const uint32_t half = side ? (round & 1u) : 0u;
+            R *res = d_res + (uint64_t)half * sub * stride;
+            if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return -7;   // K3 of round - 2 read this half
+            // K2s stores matches only: every other position of the parse must read "no match"
+            if (hipMemsetAsync(res, 0, (size_t)nb * stride * sizeof(R), stream) != hipSuccess) return -7;
+            if (!kLds && hipMemsetAsync(d_bitmap, 0, (size_t)nb * bm_stride * 4u, stream) != hipSuccess) return -7;
+            hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * 4u + 4096u * sizeof(T), stream, d_in,
+                               d_in_off, d_in_len, d_link, stride, b0, nb, max_in_len);
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
+                               static_cast<const void *>(d_link), stride, static_cast<void *>(res), d_bitmap, bm_stride, b0, nb,
+                               max_attempts, max_in_len, lk_bytes, seg_len);
+            hipStream_t emit_on = stream;
+            if (side) {
+                if (hipEventRecord(side->searched[half], stream) != hipSuccess ||
+                    hipStreamWaitEvent(side->st, side->searched[half], 0) != hipSuccess) return -7;
+                emit_on = side->st;
             }
-            if (side)     // join: everything enqueued here is ordered before whatever the caller enqueues on `stream` next
-                for (uint32_t k = 0; k < 2u && k < round; k++)
-                    if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return -7;
-            return hipGetLastError() == hipSuccess ? 0 : -7;
+            hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, emit_on, d_in, d_in_off, d_in_len,
+                               d_out, d_out_off, d_out_cap, d_result, static_cast<const R *>(res), stride, b0, nb, max_in_len);
+            if (side && hipEventRecord(side->emitted[half], side->st) != hipSuccess) return -7;
         }
+        if (side)     // join: everything enqueued here is ordered before whatever the caller enqueues on `stream` next
+            for (uint32_t k = 0; k < 2u && k < round; k++)
+                if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return -7;
+        return hipGetLastError() == hipSuccess ? 0 : -7;
     }
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
@@ -839,13 +980,15 @@ constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per round (bounds the work
 bool hc_small(uint32_t max_in_len) { return max_in_len <= 65536u; }
 uint64_t hc_per_block_bytes(uint32_t max_in_len) {
     const uint64_t chain = (((uint64_t)max_in_len + 15u) & ~15ull) * (hc_small(max_in_len) ? 6u : 12u);   // links + results
-    const uint64_t opt = zlz4_hc_opt_workspace_bytes(1);                                                     // levels 10-12
+    uint64_t opt = zlz4_hc_opt_workspace_bytes(1);                                                           // levels 10-12
+    const uint64_t bitmap = hc_small(max_in_len) ? 0 : ((((uint64_t)max_in_len + 15u) & ~15ull) / 32u + 2u) * 4u;   // visited bits (HBM links)
+    if (bitmap > opt) opt = bitmap;
     const uint64_t mid = zlz4_hc_mid_workspace_bytes(1);                                                     // level 2
     return chain + opt > mid ? chain + opt : mid;
 }
 uint32_t hc_chunk(uint32_t nblocks, uint32_t max_in_len) {
-    // keep a round's workspace around <= 2 GiB for big blocks
-    uint64_t c = (2ull << 30) / hc_per_block_bytes(max_in_len);
+    // keep the workspace around <= 6 GiB for big blocks
+    uint64_t c = (6ull << 30) / hc_per_block_bytes(max_in_len);
     if (c < 1) c = 1;
     if (c > kHcChunkBlocks) c = kHcChunkBlocks;
     if (c > nblocks) c = nblocks ? nblocks : 1;
