@@ -261,3 +261,57 @@ def test_compress_hc_ext_state(zl, oracle, gpu):
         with pytest.raises(zl.Lz4Error) as e:
             zl.compressHCExtState(bad_state, b, 9, dst_cap=cap)
         assert e.value.name == name
+
+
+def test_batch_calls_capture_into_a_hip_graph(zl, oracle, gpu):
+    """the batch calls allocate nothing and only enqueue work, so a caller can capture them into
+    a hipGraph (launch-bound inner loops).  compressFast + compressHC(9) (which forks to its side stream and joins)
+    + decompressSafe are captured once and replayed on new input; results must equal the oracle's."""
+    import torch
+    nblocks, block = 64, 65536
+    slot = (zl.compressBound(block) + 15) // 16 * 16
+    ar = torch.arange(nblocks, dtype=torch.int64, device=gpu)
+    in_off, slot_off = ar * block, ar * slot
+    in_len = torch.full((nblocks,), block, dtype=torch.int32, device=gpu)
+    cap = torch.full((nblocks,), slot, dtype=torch.int32, device=gpu)
+    inp = torch.zeros((nblocks, block), dtype=torch.uint8, device=gpu)
+    comp_f = torch.zeros(nblocks * slot, dtype=torch.uint8, device=gpu)
+    comp_h = torch.zeros(nblocks * slot, dtype=torch.uint8, device=gpu)
+    out = torch.zeros((nblocks, block), dtype=torch.uint8, device=gpu)
+    r_f = torch.zeros(nblocks, dtype=torch.int64, device=gpu)
+    r_h = torch.zeros(nblocks, dtype=torch.int64, device=gpu)
+    r_d = torch.zeros(nblocks, dtype=torch.int64, device=gpu)
+    clen = torch.zeros(nblocks, dtype=torch.int32, device=gpu)
+    ws = torch.empty(zl.batch_compress_hc_workspace(nblocks, block), dtype=torch.uint8, device=gpu)
+
+    def work():
+        zl.batch_compress_fast(inp, in_off, in_len, comp_f, slot_off, cap, r_f, block, 1)
+        zl.batch_compress_hc(inp, in_off, in_len, comp_h, slot_off, cap, r_h, block, 9, ws)
+        clen.copy_(r_h.to(torch.int32))
+        zl.batch_decompress_safe(comp_h, slot_off, clen, out, in_off, in_len, r_d)
+
+    first = torch.from_numpy(dg.make_blocks("text", nblocks, block, seed=31)).to(gpu)
+    inp.copy_(first)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        work()                                   # warm-up outside the capture (lazy module load, side stream creation)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        work()
+    second = torch.from_numpy(dg.make_blocks("mixed", nblocks, block, seed=32)).to(gpu)
+    second[: nblocks // 2] = torch.from_numpy(dg.make_blocks("text", nblocks // 2, block, seed=33)).to(gpu)
+    inp.copy_(second)
+    for t in (comp_f, comp_h, out, r_f, r_h, r_d):
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, inp) and bool((r_d == block).all())
+    host = second.cpu().numpy()
+    cf, ch = comp_f.cpu().numpy(), comp_h.cpu().numpy()
+    for i in (0, 7, nblocks // 2, nblocks - 1):
+        b = bytes(host[i])
+        assert bytes(cf[i * slot: i * slot + int(r_f[i])]) == oracle.compress_default(b), i
+        assert bytes(ch[i * slot: i * slot + int(r_h[i])]) == oracle.compress_hc(b, 9), i

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                                                          void *__restrict__ d_res_v, uint32_t *__restrict__ d_bitmap,
                                                          uint64_t bitmap_stride, uint32_t blk0, uint32_t nblocks,
                                                          int32_t max_attempts, uint32_t max_in_len, uint32_t lk_bytes,
-                                                         uint32_t seg_len) {
+                                                         uint32_t seg_len, int fetch_rounds) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     typedef typename std::conditional<kLds, uint16_t, uint32_t>::type T;
     typedef typename std::conditional<kLds, uint32_t, uint64_t>::type R;
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     bool have = false, exhausted = false, in_chain = false, in_ext = false, fresh = false;
     bool is_true = false;                                        // this lane runs the walk that started at position 0
     bool ext_final = false;                                      // `off` already is the candidate's full match length
+    uint32_t fword_next = 0;                                     // frontier word of the walk from 0, as of the previous trip
     u32x4 p16 = {0, 0, 0, 0};                                    // the 16 bytes at pos
     u32x4 aw = p16;                                              // the 16 bytes at pos + aw_off (the compare window)
     uint32_t aw_off = 0;
@@ -485,7 +486,9 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         // The walk from position 0 IS the parse as long as it has not merged into another walk; everything below its
         // frontier is settled, so start points and walks below it are dropped.  (Without this a block that begins with
         // one huge match -- zeros, a constant prefix -- would have every other lane count the same huge match.)
-        const uint32_t fword = __hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (read one trip ahead: both the frontier and the flag only ever grow, a stale value is merely less helpful)
+        const uint32_t fword = fword_next;
+        fword_next = __hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t frontier = fword & 0x7FFFFFFFu;           // (bit 31: the walk from 0 is over)
         if (have && !is_true && pos < frontier) { have = false; in_chain = false; in_ext = false; ext_final = false; }
         if (have && is_true) __hip_atomic_store(next_seg + 1, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         //      positions WITH candidates are marked and tested: walks inside the same run of candidate-less positions all
         //      reach the position that ends the run, and merge there.
         if (have && !in_chain) {
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < fetch_rounds; ++it) {
                 if (pos >= np) {
                     if (is_true) {
                         __hip_atomic_store(next_seg + 1, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -910,6 +913,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
         static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
         static const bool no_overlap = getenv("ZLZ4_HC_NO_OVERLAP") != nullptr;          // A/B switch for profiles/
+        static const int fetch_rounds = [] { const char *e = getenv("ZLZ4_HC_FETCH"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
         const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
         uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;                // ~2 start points per lane
         if (threads > 1024u) threads = 1024u;
@@ -936,7 +940,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
                                d_in_off, d_in_len, d_link, stride, b0, nb, max_in_len);
             hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
                                static_cast<const void *>(d_link), stride, static_cast<void *>(res), d_bitmap, bm_stride, b0, nb,
-                               max_attempts, max_in_len, lk_bytes, seg_len);
+                               max_attempts, max_in_len, lk_bytes, seg_len, fetch_rounds);
             hipStream_t emit_on = stream;
             if (side) {
                 if (hipEventRecord(side->searched[half], stream) != hipSuccess ||
