@@ -586,10 +586,15 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         //      lane first (lane 0 of wave 0 runs the walk from 0, whose frontier then retires the others)
         // While the walk from 0 is still on its own, the other walks do not start a long count: most likely its frontier
         // is about to retire them (a block that is one long run), and if it merges first they go on from where they are.
-        const bool walk0_over = (fword >> 31) != 0u;
-        const bool parked = have && in_chain && in_ext && !ext_final && off >= 64u && !is_true && !walk0_over;
-        {
-            uint64_t longm = ballot(have && in_chain && in_ext && !ext_final && off >= 64u && !parked);
+        // While the walk from 0 is still on its own, the other walks do not start a long count (>= 64 bytes matched): most
+        // likely its frontier is about to retire them (a block that is one long run); if it merges first they go on.  A
+        // long count is done by the whole wavefront, 1 KiB per step, lowest lane first.
+        bool parked = false;
+        if (const uint64_t wantm = ballot(have && in_chain && in_ext && !ext_final && off >= 64u)) {
+            const bool walk0_over = (fword >> 31) != 0u;
+            const bool want = (wantm >> lane) & 1ull;
+            parked = want && !is_true && !walk0_over;
+            uint64_t longm = wantm & ~ballot(parked);
             while (longm) {
                 const uint32_t L = first_lane(longm);
                 longm &= longm - 1ull;
@@ -981,7 +986,11 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
 
 namespace {
 constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per round (bounds the workspace)
-bool hc_small(uint32_t max_in_len) { return max_in_len <= 65536u; }
+bool hc_small(uint32_t max_in_len) {
+    // ZLZ4_HC_HBM_LINKS (A/B switch for profiles/): blocks <= 64 KiB through the variant that keeps the links in HBM
+    static const bool force_hbm = getenv("ZLZ4_HC_HBM_LINKS") != nullptr;
+    return max_in_len <= 65536u && !force_hbm;
+}
 uint64_t hc_per_block_bytes(uint32_t max_in_len) {
     const uint64_t chain = (((uint64_t)max_in_len + 15u) & ~15ull) * (hc_small(max_in_len) ? 6u : 12u);   // links + results
     uint64_t opt = zlz4_hc_opt_workspace_bytes(1);                                                           // levels 10-12
