@@ -29,6 +29,9 @@ def test_library_is_hip_only(zl):
     assert "libamdhip64" in out and "oracle" not in out
     blob = open(zl.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"zo_compress" not in blob
+    # the shipped library reads no environment variable (tuning knobs live in libzlz4_amd_tuning.so only)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", zl.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 def test_pure_arithmetic_entry_points(zl, oracle):

@@ -14,7 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_lane_decoder_passes_the_decoder_parity_tests(gpu):
     if os.environ.get("ZLZ4_DECOMP_LANE_MIN") == "1":
         pytest.skip("already inside the child run")
-    env = dict(os.environ, ZLZ4_DECOMP_LANE_MIN="1")
+    # the knob exists only in the tuning build of the library (the shipped one reads no environment variable)
+    tuning = os.path.join(ROOT, "zig-lz4_amd", "libzlz4_amd_tuning.so")
+    assert os.path.exists(tuning), "make tuning"
+    env = dict(os.environ, ZLZ4_DECOMP_LANE_MIN="1", ZLZ4_AMD_LIB=tuning)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_frame.py"),
                         "-k", "decompress or batch_of or single_buffer or interop"],

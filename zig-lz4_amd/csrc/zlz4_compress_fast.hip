@@ -642,12 +642,12 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
                                          uint32_t max_in_len, uint32_t acceleration) {
     if (nblocks == 0) return 0;
     // experiment knob: extra dynamic LDS per workgroup lowers the number of resident waves per CU
-    static const uint32_t lds_pad = [] { const char *e = getenv("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t lds_pad = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
     // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
-    static const uint32_t tune_wpw = [] { const char *e = getenv("ZLZ4_TUNE_WPW"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t tune_wpw = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_WPW"); return e ? (uint32_t)atoi(e) : 0u; }();
     // lane at which a window that already holds a match stops and hands over to the next window (any value 1..64 gives
     // the same bytes; it trades sequences per window against re-probed lanes)
-    static const uint32_t restart = [] { const char *e = getenv("ZLZ4_TUNE_RESTART"); const uint32_t v = e ? (uint32_t)atoi(e) : 64u;
+    static const uint32_t restart = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_RESTART"); const uint32_t v = e ? (uint32_t)atoi(e) : 64u;
                                          return v >= 1u && v <= 64u ? v : 64u; }();
     if (max_in_len <= 65536u + 11u) {
         // 8 KiB of LDS per wavefront -> 20 wavefronts per CU whatever the workgroup size; one-wave workgroups measured

@@ -909,23 +909,23 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * 4u + 4096u * sizeof(T)));
-    static const bool legacy_search = getenv("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
+    static const bool legacy_search = zlz4_tune_env("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
     const bool seg_search = !optimal && !legacy_search;
     if (seg_search) {
         // parse-aware search (k_hc_seg_search).  Rounds of half a chunk, results in the two halves of the result
         // area in turn: K3 of round r runs on the side stream while K1 / K2s of round r + 1 run on `stream`.
         constexpr bool kLds = sizeof(T) == 2;
-        static const uint32_t seg_len = [] { const char *e = getenv("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
-        static const uint32_t thr_div = [] { const char *e = getenv("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
-        static const bool no_overlap = getenv("ZLZ4_HC_NO_OVERLAP") != nullptr;          // A/B switch for profiles/
-        static const int fetch_rounds = [] { const char *e = getenv("ZLZ4_HC_FETCH"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+        static const uint32_t seg_len = [] { const char *e = zlz4_tune_env("ZLZ4_HC_SEG"); return e ? (uint32_t)atoi(e) : 32u; }();   // start points of the speculative walks
+        static const uint32_t thr_div = [] { const char *e = zlz4_tune_env("ZLZ4_HC_LPS"); return e ? (uint32_t)atoi(e) : 2u; }();
+        static const bool no_overlap = zlz4_tune_env("ZLZ4_HC_NO_OVERLAP") != nullptr;          // A/B switch for profiles/
+        static const int fetch_rounds = [] { const char *e = zlz4_tune_env("ZLZ4_HC_FETCH"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
         const uint32_t nseg_max = (np_max + seg_len - 1u) / seg_len;
         uint32_t threads = (nseg_max / thr_div + 63u) & ~63u;                // ~2 start points per lane
         if (threads > 1024u) threads = 1024u;
         if (threads < 64u) threads = 64u;
         const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
         const uint32_t lds = kLds ? lk_bytes + ((np_max + 31u) / 32u + 3u) * 4u : 16u;
-        static const int cands = [] { const char *e = getenv("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
+        static const int cands = [] { const char *e = zlz4_tune_env("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
         auto kern = cands == 4 ? &k_hc_seg_search<4, kLds> : cands == 2 ? &k_hc_seg_search<2, kLds> : &k_hc_seg_search<1, kLds>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const uint64_t bm_stride = (stride + 31u) / 32u + 1u;                // bitmap words per block (HBM links only)
@@ -988,7 +988,7 @@ namespace {
 constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per round (bounds the workspace)
 bool hc_small(uint32_t max_in_len) {
     // ZLZ4_HC_HBM_LINKS (A/B switch for profiles/): blocks <= 64 KiB through the variant that keeps the links in HBM
-    static const bool force_hbm = getenv("ZLZ4_HC_HBM_LINKS") != nullptr;
+    static const bool force_hbm = zlz4_tune_env("ZLZ4_HC_HBM_LINKS") != nullptr;
     return max_in_len <= 65536u && !force_hbm;
 }
 uint64_t hc_per_block_bytes(uint32_t max_in_len) {

@@ -552,25 +552,25 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
     if (nblocks == 0) return 0;
     // one wavefront per block (batch path) is the faster decoder at every batch size measured on MI355X; the
     // one-lane-per-block kernel stays available behind ZLZ4_DECOMP_LANE_MIN (tests/test_gpu_lane_decoder.py)
-    static const uint32_t lane_min = [] { const char *e = getenv("ZLZ4_DECOMP_LANE_MIN"); return e ? (uint32_t)atoll(e) : 0xFFFFFFFFu; }();
+    static const uint32_t lane_min = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_LANE_MIN"); return e ? (uint32_t)atoll(e) : 0xFFFFFFFFu; }();
     if (nblocks >= lane_min) {
         // the kernel is latency-bound: with few blocks use fewer lanes per wavefront so that ~8192 wavefronts exist
-        static const uint32_t lanes_env = [] { const char *e = getenv("ZLZ4_DECOMP_LANES"); return e ? (uint32_t)atoi(e) : 0u; }();
+        static const uint32_t lanes_env = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_LANES"); return e ? (uint32_t)atoi(e) : 0u; }();
         // measured on MI355X (65 536 blocks): 16 or 32 active lanes per wavefront are ~5 % faster than 64
         uint32_t lanes = nblocks >= 524288u ? 64u : (nblocks >= 262144u ? 32u : 16u);
         if (lanes_env >= 1 && lanes_env <= 64) lanes = lanes_env;
-        static const uint32_t max_lanes = [] { const char *e = getenv("ZLZ4_DECOMP_MAXLANES"); return e ? (uint32_t)atoll(e) : 0u; }();
+        static const uint32_t max_lanes = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_MAXLANES"); return e ? (uint32_t)atoll(e) : 0u; }();
         uint32_t grid = (nblocks + lanes - 1u) / lanes;
         if (max_lanes && (uint64_t)grid * lanes > max_lanes) grid = (max_lanes + lanes - 1u) / lanes;
         hipLaunchKernelGGL(zlz4::k_decompress_lane, dim3(grid), dim3(lanes), 0, stream, d_in, d_in_off,
                            d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
         return hipGetLastError() == hipSuccess ? 0 : -7;
     }
-    static const uint32_t waves_per_wg = [] { const char *e = getenv("ZLZ4_DECOMP_WPW"); const uint32_t v = e ? (uint32_t)atoi(e) : 4u;
+    static const uint32_t waves_per_wg = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_WPW"); const uint32_t v = e ? (uint32_t)atoi(e) : 4u;
                                               return (v == 1u || v == 2u || v == 4u) ? v : 4u; }();
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
     // experiment knob: dynamic LDS per workgroup only to limit the number of resident wavefronts per CU
-    static const uint32_t dyn_lds = [] { const char *e = getenv("ZLZ4_DECOMP_LDS"); return e ? (uint32_t)atoll(e) : 0u; }();
+    static const uint32_t dyn_lds = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_LDS"); return e ? (uint32_t)atoll(e) : 0u; }();
     hipLaunchKernelGGL(zlz4::k_decompress_safe<true>, dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in, d_in_off,
                        d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
     return hipGetLastError() == hipSuccess ? 0 : -7;

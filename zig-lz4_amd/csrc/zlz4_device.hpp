@@ -6,6 +6,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Experiment / A-B knobs exist only in the diagnostic builds (-DZLZ4_TUNING: `make tuning`,
+// `make stamps`); the shipped library reads no environment variable.
+#ifdef ZLZ4_TUNING
+static inline const char *zlz4_tune_env(const char *name) { return getenv(name); }
+#else
+static inline const char *zlz4_tune_env(const char *) { return nullptr; }
+#endif
 
 namespace zlz4 {
 
