@@ -365,7 +365,8 @@ extern "C" int zlz4_launch_hc_mid(hipStream_t stream, const uint8_t *d_in, const
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
         if (hipMemsetAsync(ws, 0, zlz4_hc_mid_workspace_bytes(nb), stream) != hipSuccess) return -7;   // :725-726
-        hipLaunchKernelGGL(zlz4::k_hc_mid_serial, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len, d_out,
+        static const uint32_t lanes = [] { const char *e = zlz4_tune_env("ZLZ4_MID_LANES"); const uint32_t v = e ? (uint32_t)atoi(e) : 1u; return v >= 1u && v <= 64u ? v : 1u; }();
+        hipLaunchKernelGGL(zlz4::k_hc_mid_serial, dim3((nb + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off, d_in_len, d_out,
                            d_out_off, d_out_cap, d_result, static_cast<uint32_t *>(ws), b0, nb);
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
@@ -377,12 +378,13 @@ extern "C" int zlz4_launch_hc_opt_parse(hipStream_t stream, const uint8_t *d_in,
                                         const uint32_t *d_out_cap, int64_t *d_result, const void *d_res, uint64_t res_stride,
                                         int wide, void *d_opt, uint32_t b0, uint32_t nb, uint32_t sufficient_len,
                                         uint32_t max_in_len) {
+    static const uint32_t lanes = [] { const char *e = zlz4_tune_env("ZLZ4_OPT_LANES"); const uint32_t v = e ? (uint32_t)atoi(e) : 1u; return v >= 1u && v <= 64u ? v : 1u; }();
     if (wide)
-        hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint64_t>, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len,
+        hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint64_t>, dim3((nb + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off, d_in_len,
                            d_out, d_out_off, d_out_cap, d_result, static_cast<const uint64_t *>(d_res), res_stride,
                            static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len, max_in_len);
     else
-        hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint32_t>, dim3((nb + 63u) / 64u), dim3(64), 0, stream, d_in, d_in_off, d_in_len,
+        hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint32_t>, dim3((nb + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off, d_in_len,
                            d_out, d_out_off, d_out_cap, d_result, static_cast<const uint32_t *>(d_res), res_stride,
                            static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len, max_in_len);
     return hipGetLastError() == hipSuccess ? 0 : -7;

@@ -469,11 +469,17 @@ __global__ void k_mask_stored(uint32_t *data_len_for_decode, const uint32_t *dat
     }
 }
 
-// content checksum over dst[0, total) with total read from the device (total_p[0]); only when no error is pending
-__global__ void k_content_check(const uint8_t *dst, const int64_t *total_p, const uint8_t *stored, int64_t *dplan) {
+// content checksum over dst[0, total) with total read from the device (total_p[0]); only when no error is pending,
+// and -- on the speculative path (need_proven) -- only when the layout guess has been proven: an unproven total can
+// be anything a corrupted frame says (and XXH32 of gigabytes on one lane takes seconds)
+__global__ void k_content_check(const uint8_t *dst, const int64_t *total_p, const uint8_t *stored, int64_t *dplan,
+                                uint32_t need_proven, uint64_t dst_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (dplan[1] != 0) return;
-    if (xxh32(dst, (uint64_t)total_p[0], 0) != zx_rd32(stored)) dplan[1] = ZLZ4F_ERR_CONTENT_CHECKSUM_INVALID;   // :631
+    if (need_proven && dplan[2] != 1) return;
+    const uint64_t total = (uint64_t)total_p[0];
+    if (total > dst_cap) return;
+    if (xxh32(dst, total, 0) != zx_rd32(stored)) dplan[1] = ZLZ4F_ERR_CONTENT_CHECKSUM_INVALID;   // :631
 }
 
 int64_t map_block_error(int64_t e) {     // mapCompressionError, src/lz4f.zig:144-149
@@ -647,7 +653,8 @@ int64_t decompress_frame_impl(hipStream_t st, const uint8_t *d_src, size_t n, ui
             hipLaunchKernelGGL(k_dframe_check, dim3(1), dim3(64), 0, st, data_len, flags, d_sz.as<int64_t>(), cks_ok, out_cap, bc,
                                nb, bs, walk, dplan);
             if (cc && src_pos_end + 4 <= n)     // only meaningful when the guess holds; checked below
-                hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan);
+                hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan, 1u,
+                                   (uint64_t)cap);
             if (hipMemcpyAsync(plan_host, dplan, sizeof plan_host, hipMemcpyDeviceToHost, st) != hipSuccess || !fc.sync())
                 return ZLZ4_ERR_DEVICE;
             if (plan_host[2] == 1) {
@@ -683,7 +690,8 @@ int64_t decompress_frame_impl(hipStream_t st, const uint8_t *d_src, size_t n, ui
             int64_t tot[2] = {plan_host[0], 0};
             if (hipMemcpyAsync(dplan, tot, sizeof tot, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
             fc.launched();
-            hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan);
+            hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan, 0u,
+                               (uint64_t)cap);
             if (hipMemcpyAsync(plan_host, dplan, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
         }
         if (!fc.sync() || hipGetLastError() != hipSuccess) return ZLZ4_ERR_DEVICE;
