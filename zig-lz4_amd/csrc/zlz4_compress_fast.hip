@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_compress_fast(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
     const uint64_t *__restrict__ d_out_off, const uint32_t *__restrict__ d_out_cap,
-    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration, uint32_t tune_restart, uint32_t max_in_len) {
+    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration, uint32_t max_in_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_wg = threadIdx.x >> 6;
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
         STAMP_DECL
         STAMP(0);   // table init
 
-        // a window that has produced a match hands over to the next one once the search front passes this lane
-        const uint32_t restart_lane = rfl(tune_restart);
+        // a window keeps going to its last lane (handing over to the next window earlier, once it holds a match, was
+        // measured at every lane: 49 -> 55.6 ms, 64 -> 46.8 ms on configs[1]; any choice gives the same bytes)
         uint32_t guard = 0;      // every round of this loop consumes at least one input byte
         // forward bytes of the next window, loaded as soon as its anchor is known (before the emission and the table
         // fix-up of the current window, which hide the load)
@@ -326,40 +326,39 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     //      window (its probe reads the pre-window value whatever was put before) and the literal
                     //      run fits the token nibble. ----
                     if (mm_run == 0) { a0 = a; op0 = op; }
-                    // (the restart threshold 49 only applies once the window has produced a match: a window without
-                    //  any match must scan all 64 lanes and hand the search over to the generic path)
                     if (!tight) {
                         // hand-scheduled scalar loop (the compiler spends ~25 scalar instructions per trip on the
                         // boolean plumbing; the scalar unit is what bounds this kernel):
-                        //   while (f < 64 && (f < 49 || nseq == 0)) { pk = PK[f]; j = pk & 63; if (pk == ~0) break;
-                        //                                               mm_run |= 1 << j; nseq++; a = pk >> 6; f = a + 1; }
+                        //   while (f < 64) { pk = PK[f]; j = pk & 63; if (pk == ~0) break;
+                        //                    mm_run |= 1 << j; nseq++; a = pk >> 6; f = a + 1; }          (two trips per branch back)
                         uint32_t t_pk, t_j;
+#define ZLZ4_FAST_RUN_TRIP                                   \
+                            "s_cmp_gt_u32 %[f], 63\n\t"      \
+                            "s_cbranch_scc1 3f\n\t"          \
+                            "v_readlane_b32 %[pk], %[PK], %[f]\n\t" \
+                            "s_cmp_eq_u32 %[pk], -1\n\t"     \
+                            "s_cbranch_scc1 3f\n\t"          \
+                            "s_lshr_b32 %[a], %[pk], 6\n\t"  \
+                            "s_add_u32 %[f], %[a], 1\n\t"    \
+                            "s_and_b32 %[j], %[pk], 63\n\t"  \
+                            "s_bitset1_b64 %[mm], %[j]\n\t"  \
+                            "s_add_u32 %[nseq], %[nseq], 1\n\t"
+                        // (five scalar instructions lie between the write of f and the v_readlane that uses it as its lane
+                        //  select: the ISA asks for four wait states there)
                         asm volatile(
                             "s_nop 3\n"
                             "1:\n\t"
-                            "s_cmp_gt_u32 %[f], 63\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "s_cmp_lt_u32 %[f], %[rs]\n\t"
-                            "s_cbranch_scc1 2f\n\t"
-                            "s_cmp_eq_u32 %[nseq], 0\n\t"
-                            "s_cbranch_scc0 3f\n"
-                            "2:\n\t"
-                            "v_readlane_b32 %[pk], %[PK], %[f]\n\t"
-                            "s_cmp_eq_u32 %[pk], -1\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "s_and_b32 %[j], %[pk], 63\n\t"
-                            "s_bitset1_b64 %[mm], %[j]\n\t"
-                            "s_add_u32 %[nseq], %[nseq], 1\n\t"
-                            "s_lshr_b32 %[a], %[pk], 6\n\t"
-                            "s_add_u32 %[f], %[a], 1\n\t"
+                            ZLZ4_FAST_RUN_TRIP
+                            ZLZ4_FAST_RUN_TRIP
                             "s_branch 1b\n"
                             "3:\n"
                             : [f] "+s"(f), [a] "+s"(a), [nseq] "+s"(nseq), [mm] "+s"(mm_run), [pk] "=&s"(t_pk), [j] "=&s"(t_j)
-                            : [PK] "v"(PK), [rs] "s"(restart_lane)
+                            : [PK] "v"(PK)
                             : "scc");
+#undef ZLZ4_FAST_RUN_TRIP
                     }
                     STAMP(8);
-                    if (f >= 64u || (f >= restart_lane && nseq > 0u)) {      // window done (a = last anchor lane, possibly >= 64)
+                    if (f >= 64u) {      // window done (a = last anchor lane, possibly >= 64)
                         if (nseq == 0u) continue_generic = true;    // every lane probed, no match
                         break;
                     }
@@ -645,10 +644,6 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
     static const uint32_t lds_pad = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
     // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
     static const uint32_t tune_wpw = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_WPW"); return e ? (uint32_t)atoi(e) : 0u; }();
-    // lane at which a window that already holds a match stops and hands over to the next window (any value 1..64 gives
-    // the same bytes; it trades sequences per window against re-probed lanes)
-    static const uint32_t restart = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_RESTART"); const uint32_t v = e ? (uint32_t)atoi(e) : 64u;
-                                         return v >= 1u && v <= 64u ? v : 64u; }();
     if (max_in_len <= 65536u + 11u) {
         // 8 KiB of LDS per wavefront -> 20 wavefronts per CU whatever the workgroup size; one-wave workgroups measured
         // 5 % faster than four-wave ones on MI355X (44.1 / 45.0 / 46.6 ms for 1 / 2 / 4 on configs[1]): a finished
@@ -656,12 +651,12 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
         const uint32_t wpw = (tune_wpw == 2 || tune_wpw == 4) ? tune_wpw : 1;
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint16_t) + lds_pad, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration, restart, max_in_len);
+                           d_out_cap, d_result, nblocks, acceleration, max_in_len);
     } else {
         const uint32_t wpw = (tune_wpw == 2) ? 2 : 1;   // 16 KiB of LDS per wavefront -> 10 wavefronts per CU
         hipLaunchKernelGGL(zlz4::k_compress_fast<uint32_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
                            wpw * 4096 * sizeof(uint32_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration, restart, max_in_len);
+                           d_out_cap, d_result, nblocks, acceleration, max_in_len);
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }

@@ -104,20 +104,37 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
     constexpr uint32_t kSub = 4;                        // 64-position groups per step
-    uint32_t seq_next[kSub];
-    for (uint32_t j = 0; j < kSub; j++) seq_next[j] = lane + 64u * j < np ? ld32(src + lane + 64u * j) : 0u;
-    for (uint32_t base = 0; base < np; base += 64u * kSub) {
-        uint32_t seq[kSub], old[kSub];
-        for (uint32_t j = 0; j < kSub; j++) seq[j] = seq_next[j];
-        for (uint32_t j = 0; j < kSub; j++) {           // next step's bytes are in flight during this step
-            const uint32_t qn = base + 64u * (kSub + j) + lane;
-            if (qn < np) seq_next[j] = ld32(src + qn);
+    // one wavefront per CU has nothing else to hide the input loads behind: the bytes of a step are requested kDepth
+    // steps ahead (one step is ~700 cycles of work, an HBM miss ~2000)
+    constexpr uint32_t kDepth = 3;
+    uint32_t seq_pf[kDepth][kSub];
+#pragma unroll
+    for (uint32_t d = 0; d < kDepth; d++)
+#pragma unroll
+        for (uint32_t j = 0; j < kSub; j++) {
+            const uint32_t q0 = 64u * (kSub * d + j) + lane;
+            seq_pf[d][j] = q0 < np ? ld32(src + q0) : 0u;
         }
+    for (uint32_t base0 = 0; base0 < np; base0 += 64u * kSub * kDepth) {
+#pragma unroll
+      for (uint32_t d = 0; d < kDepth; d++) {
+        const uint32_t base = base0 + 64u * kSub * d;
+        if (base >= np) break;
+        uint32_t seq[kSub], old[kSub];
+#pragma unroll
+        for (uint32_t j = 0; j < kSub; j++) seq[j] = seq_pf[d][j];
+#pragma unroll
+        for (uint32_t j = 0; j < kSub; j++) {           // the bytes of the step kDepth steps ahead
+            const uint32_t qn = base + 64u * (kSub * kDepth + j) + lane;
+            if (qn < np) seq_pf[d][j] = ld32(src + qn);
+        }
+#pragma unroll
         for (uint32_t j = 0; j < kSub; j++) {           // in position order: LDS operations of a wavefront keep their order
             const uint32_t q = base + 64u * j + lane;
             old[j] = 0;
             if (q < np) old[j] = __hip_atomic_fetch_max(table + hash_hc(seq[j]), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#pragma unroll
         for (uint32_t j = 0; j < kSub; j++) {
             const uint32_t q = base + 64u * j + lane;
             const bool active = q < np;
@@ -154,6 +171,7 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
             for (uint32_t k = lane; k < n16; k += 64u) g4[k] = s4[k];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
+      }
     }
 }
 
