@@ -73,15 +73,21 @@ __device__ __forceinline__ uint32_t n_positions(uint32_t n) { return n < kMfLimi
 // smaller than every position of the step).  `old < q` on all lanes therefore PROVES the ascending order; otherwise the
 // group is resolved by ballot (prev of a member = the nearest lower member, else the smallest value anyone in the group
 // read, which is the pre-step value).  The 32768-entry table is 32-bit for every block size (LDS atomics are): 128 KiB,
-// one wavefront and one block per CU; k_hc_parse_emit of the previous round fills the rest of the machine.
+// one block per CU.  Four wavefronts share the block: wavefront w takes the steps s = w (mod 4) and does everything of
+// a step -- input bytes (requested kDepth of its steps ahead), hashes, order check, link staging -- on its own; only the
+// four atomics of a step wait for their turn (an LDS counter: step s goes when the atomics of step s - 1 have RETURNED),
+// which is what keeps the insertions in position order.  k_hc_parse_emit of the previous round fills the rest of the
+// machine.
+constexpr uint32_t kLinkWaves = 4;
 template <typename T>
-__global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict__ d_in,
-                                                        const uint64_t *__restrict__ d_in_off,
-                                                        const uint32_t *__restrict__ d_in_len, T *__restrict__ d_link,
-                                                        uint64_t link_stride, uint32_t blk0, uint32_t nblocks,
-                                                        uint32_t max_in_len) {
+__global__ __launch_bounds__(64 * kLinkWaves) void k_hc_build_links(const uint8_t *__restrict__ d_in,
+                                                                     const uint64_t *__restrict__ d_in_off,
+                                                                     const uint32_t *__restrict__ d_in_len,
+                                                                     T *__restrict__ d_link, uint64_t link_stride,
+                                                                     uint32_t blk0, uint32_t nblocks, uint32_t max_in_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const uint8_t *src = d_in + d_in_off[blk0 + b];
@@ -91,87 +97,100 @@ __global__ __launch_bounds__(64) void k_hc_build_links(const uint8_t *__restrict
     T *link = d_link + (uint64_t)b * link_stride;
     typedef __attribute__((address_space(3))) uint32_t lds_slot;
     typedef __attribute__((address_space(3))) T lds_link;
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_turn;
     lds_slot *table = (lds_slot *)lds_raw;
     // links are staged in LDS and written out 4096 at a time with 16-byte stores: a global store per step would sit in
     // the same in-order queue as the prefetch loads and make every step wait for HBM writes
     constexpr uint32_t kStage = 4096;
     lds_link *stage = (lds_link *)(lds_raw + kHcTableSize * 4u);
+    lds_turn *turn = (lds_turn *)(lds_raw + kHcTableSize * 4u + kStage * sizeof(T));
     {
         u32x4 z = {0, 0, 0, 0};
         u32x4 *t4 = reinterpret_cast<u32x4 *>(lds_raw);
-        for (uint32_t k = lane; k < kHcTableSize * 4u / 16u; k += 64u) t4[k] = z;   // Context.init :405-419
+        for (uint32_t k = threadIdx.x; k < kHcTableSize * 4u / 16u; k += 64u * kLinkWaves) t4[k] = z;   // Context.init :405-419
+        if (threadIdx.x == 0) *turn = 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __syncthreads();
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
     constexpr uint32_t kSub = 4;                        // 64-position groups per step
-    // one wavefront per CU has nothing else to hide the input loads behind: the bytes of a step are requested kDepth
-    // steps ahead (one step is ~700 cycles of work, an HBM miss ~2000)
-    constexpr uint32_t kDepth = 3;
+    constexpr uint32_t kStep = 64u * kSub;              // positions per step
+    constexpr uint32_t kDepth = 2;                      // steps of THIS wavefront whose bytes are in flight
+    constexpr uint32_t kStepsPerChunk = kStage / kStep; // 16 steps fill the staging area: 4 per wavefront
     uint32_t seq_pf[kDepth][kSub];
 #pragma unroll
     for (uint32_t d = 0; d < kDepth; d++)
 #pragma unroll
         for (uint32_t j = 0; j < kSub; j++) {
-            const uint32_t q0 = 64u * (kSub * d + j) + lane;
+            const uint32_t q0 = kStep * (wave + kLinkWaves * d) + 64u * j + lane;
             seq_pf[d][j] = q0 < np ? ld32(src + q0) : 0u;
         }
-    for (uint32_t base0 = 0; base0 < np; base0 += 64u * kSub * kDepth) {
+    const uint32_t nsteps = (np + kStep - 1u) / kStep;
+    for (uint32_t c0 = 0; c0 < nsteps; c0 += kStepsPerChunk) {
+        // the steps of this chunk that belong to this wavefront: c0 + wave, + 4, + 8, + 12  (kDepth divides their number)
 #pragma unroll
-      for (uint32_t d = 0; d < kDepth; d++) {
-        const uint32_t base = base0 + 64u * kSub * d;
-        if (base >= np) break;
-        uint32_t seq[kSub], old[kSub];
+        for (uint32_t k = 0; k < kStepsPerChunk / kLinkWaves; k++) {
+            const uint32_t d = k % kDepth;
+            const uint32_t step = c0 + wave + kLinkWaves * k;
+            if (step >= nsteps) break;
+            const uint32_t base = step * kStep;
+            uint32_t seq[kSub], old[kSub];
 #pragma unroll
-        for (uint32_t j = 0; j < kSub; j++) seq[j] = seq_pf[d][j];
+            for (uint32_t j = 0; j < kSub; j++) seq[j] = seq_pf[d][j];
 #pragma unroll
-        for (uint32_t j = 0; j < kSub; j++) {           // the bytes of the step kDepth steps ahead
-            const uint32_t qn = base + 64u * (kSub * kDepth + j) + lane;
-            if (qn < np) seq_pf[d][j] = ld32(src + qn);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kSub; j++) {           // in position order: LDS operations of a wavefront keep their order
-            const uint32_t q = base + 64u * j + lane;
-            old[j] = 0;
-            if (q < np) old[j] = __hip_atomic_fetch_max(table + hash_hc(seq[j]), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kSub; j++) {
-            const uint32_t q = base + 64u * j + lane;
-            const bool active = q < np;
-            uint32_t prev = old[j];
-            uint64_t viol = ballot(active && prev >= q && q != 0u);   // (position 0 reads the empty slot: prev = 0 is right)
-            if (viol) {
-                // the lanes of some group were not served in ascending order: resolve those groups by ballot
-                const uint32_t h = hash_hc(seq[j]);
-                while (viol) {
-                    const uint32_t hh = rdlane(h, first_lane(viol));
-                    const uint64_t same = ballot(active && h == hh);
-                    uint32_t pre = 0xFFFFFFFFu;           // the pre-step value: the smallest value any member read
-                    for (uint64_t r = same; r; r &= r - 1ull) {
-                        const uint32_t o = rdlane(old[j], first_lane(r));
-                        pre = o < pre ? o : pre;
-                    }
-                    if (active && h == hh) {
-                        const uint64_t below = same & lanes_below;
-                        prev = below ? base + 64u * j + (63u - (uint32_t)__clzll((long long)below)) : pre;
-                    }
-                    viol &= ~same;
-                }
+            for (uint32_t j = 0; j < kSub; j++) {       // the bytes of this wavefront's step kDepth steps ahead
+                const uint32_t qn = base + kStep * kLinkWaves * kDepth + 64u * j + lane;
+                if (qn < np) seq_pf[d][j] = ld32(src + qn);
             }
-            if (active) stage[q & (kStage - 1u)] = Links<T>::make(q, prev);   // :502-504 (clamp applied on read for T = u32)
+            uint32_t hsh[kSub];
+#pragma unroll
+            for (uint32_t j = 0; j < kSub; j++) hsh[j] = hash_hc(seq[j]);
+            while (*turn != step) __builtin_amdgcn_s_sleep(1);       // the atomics of step - 1 are done
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (uint32_t j = 0; j < kSub; j++) {       // in position order: LDS operations of a wavefront keep their order
+                const uint32_t q = base + 64u * j + lane;
+                old[j] = 0;
+                if (q < np) old[j] = __hip_atomic_fetch_max(table + hsh[j], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the hand-over stays behind the four atomics
+            if (lane == 0) *turn = step + 1u;
+#pragma unroll
+            for (uint32_t j = 0; j < kSub; j++) {
+                const uint32_t q = base + 64u * j + lane;
+                const bool active = q < np;
+                uint32_t prev = old[j];
+                uint64_t viol = ballot(active && prev >= q && q != 0u);   // (position 0 reads the empty slot: prev = 0 is right)
+                if (viol) {
+                    // the lanes of some group were not served in ascending order: resolve those groups by ballot
+                    const uint32_t h = hsh[j];
+                    while (viol) {
+                        const uint32_t hh = rdlane(h, first_lane(viol));
+                        const uint64_t same = ballot(active && h == hh);
+                        uint32_t pre = 0xFFFFFFFFu;       // the pre-step value: the smallest value any member read
+                        for (uint64_t r = same; r; r &= r - 1ull) {
+                            const uint32_t o = rdlane(old[j], first_lane(r));
+                            pre = o < pre ? o : pre;
+                        }
+                        if (active && h == hh) {
+                            const uint64_t below = same & lanes_below;
+                            prev = below ? base + 64u * j + (63u - (uint32_t)__clzll((long long)below)) : pre;
+                        }
+                        viol &= ~same;
+                    }
+                }
+                if (active) stage[q & (kStage - 1u)] = Links<T>::make(q, prev);   // :502-504 (clamp applied on read for T = u32)
+            }
         }
-        const uint32_t done_to = base + 64u * kSub;      // positions below this are staged
-        if ((done_to & (kStage - 1u)) == 0u || done_to >= np) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const uint32_t cb = (done_to - 1u) & ~(kStage - 1u);                // first position of the staged chunk
-            const uint32_t cnt = (done_to < np ? done_to : np) - cb;
-            const uint32_t n16 = (cnt * (uint32_t)sizeof(T) + 15u) >> 4;       // (the link array is padded to 16 entries)
+        __syncthreads();                                 // every step of the chunk is staged
+        {
+            const uint32_t cb = c0 * kStep;                                     // first position of the staged chunk
+            const uint32_t ce = cb + kStage < np ? cb + kStage : np;
+            const uint32_t n16 = ((ce - cb) * (uint32_t)sizeof(T) + 15u) >> 4;  // (the link array is padded to 16 entries)
             const u32x4 *s4 = reinterpret_cast<const u32x4 *>(lds_raw + kHcTableSize * 4u);
             u32x4 *g4 = reinterpret_cast<u32x4 *>(link + cb);
-            for (uint32_t k = lane; k < n16; k += 64u) g4[k] = s4[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (uint32_t k = threadIdx.x; k < n16; k += 64u * kLinkWaves) g4[k] = s4[k];
         }
-      }
+        __syncthreads();                                 // the staging area may be overwritten
     }
 }
 
@@ -926,7 +945,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     const uint32_t np_max = max_in_len < 13u ? 1u : max_in_len - 11u;
     // 128 KiB of the CU's 160 KiB LDS for the 32-bit table
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hc_build_links<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * 4u + 4096u * sizeof(T)));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHcTableSize * 4u + 4096u * sizeof(T) + 16u));
     static const bool legacy_search = zlz4_tune_env("ZLZ4_HC_LEGACY_SEARCH") != nullptr;   // A/B switch for profiles/
     const bool seg_search = !optimal && !legacy_search;
     if (seg_search) {
@@ -959,7 +978,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
             // K2s stores matches only: every other position of the parse must read "no match"
             if (hipMemsetAsync(res, 0, (size_t)nb * stride * sizeof(R), stream) != hipSuccess) return -7;
             if (!kLds && hipMemsetAsync(d_bitmap, 0, (size_t)nb * bm_stride * 4u, stream) != hipSuccess) return -7;
-            hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * 4u + 4096u * sizeof(T), stream, d_in,
+            hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64 * kLinkWaves), kHcTableSize * 4u + 4096u * sizeof(T) + 16u, stream, d_in,
                                d_in_off, d_in_len, d_link, stride, b0, nb, max_in_len);
             hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
                                static_cast<const void *>(d_link), stride, static_cast<void *>(res), d_bitmap, bm_stride, b0, nb,
@@ -981,7 +1000,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
     }
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
-        hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64), kHcTableSize * 4u + 4096u * sizeof(T), stream, d_in, d_in_off,
+        hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64 * kLinkWaves), kHcTableSize * 4u + 4096u * sizeof(T) + 16u, stream, d_in, d_in_off,
                            d_in_len, d_link, stride, b0, nb, max_in_len);
         // every position (the price-based parse of levels 10-12 looks results up everywhere; blocks > 64 KiB)
         // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
