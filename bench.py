@@ -351,8 +351,8 @@ def main():
         comp_gibs = None if decomp_only else total_n / (tc_ms * 1e-3) / GIB
         dec_gibs = total_n / (td_ms * 1e-3) / GIB
         hc_kernels = ("zlz4::k_hc_mid_serial" if args.level <= 2 else
-                      "HC pipeline: k_hc_build_links + k_hc_seg_search<4> + k_hc_parse_emit (x4 rounds of 4096 blocks)" if args.level <= 9 else
-                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse (x4 rounds of 4096 blocks)")
+                      "HC pipeline: k_hc_build_links + k_hc_seg_search<4> + k_hc_parse_emit (rounds of 2048 blocks, emit beside the next round)" if args.level <= 9 else
+                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse (rounds of 4096 blocks)")
         kc = {"cfg2": "zlz4::k_compress_fast<uint16_t>", "cfg4": hc_kernels,
               "cfg5": "zlz4::k_compress_fast<uint32_t>", "cfg3": None}[args.workload]
         if decomp_only:
