@@ -103,6 +103,23 @@ def test_compress_hc_bit_exact(zl, oracle, gpu, level):
     _cmp([n for n, _ in sel], got, want)
 
 
+@pytest.mark.parametrize("level", [3, 9, 12])
+def test_compress_hc_link_build_step_boundaries(zl, oracle, gpu, level):
+    """k_hc_build_links hands 256-position steps round robin to four wavefronts and flushes its staging area every 4096
+    positions: block sizes whose number of insertable positions (n - 11) sits on and around those boundaries, on both
+    sides of the 16-bit / 32-bit link switch (65547 / 65548 bytes)."""
+    sizes = [266, 267, 268, 523, 1034, 1035, 1036, 1291, 4106, 4107, 4108, 8203, 12299, 12300, 65547, 65548, 69643, 69644]
+    if level != 12:
+        sizes += [131083, 131084]
+    names, items = [], []
+    for dist in ("text", "mixed", "reptext"):
+        for n in sizes:
+            names.append("%s/%d" % (dist, n)); items.append(bytes(dg.GENERATORS[dist](n, 31 + n)))
+    got = gh.compress_hc(zl, items, gpu, level)
+    want = [oracle.compress_hc(b, level) for b in items]
+    _cmp(names, got, want)
+
+
 def test_compress_output_too_small_parity(zl, oracle, gpu):
     """Destination smaller than the bound: identical OutputTooSmall / success decision (Appendix A Q10, H7)."""
     names, items, caps = [], [], []
