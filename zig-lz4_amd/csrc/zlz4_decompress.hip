@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
         auto flush_pending = [&]() {
             if (!kWrite) return;
             if (pml != 0) {
-                uint8_t *o = dst + po;
+                // (every address is dst + a 32-bit offset: the uniform base stays in scalar registers and no lane
+                //  spends vector instructions on 64-bit pointer arithmetic)
                 if (pml >= 16u) {
-                    st128(o, pa);
-                    for (uint32_t k = 16u; k + 16u <= pml; k += 16u) st128(o + k, ld128(o - pof + k));
-                    st128(o + pml - 16u, pb);
+                    st128(dst + po, pa);
+                    for (uint32_t k = 16u; k + 16u <= pml; k += 16u) st128(dst + (po + k), ld128(dst + (po - pof + k)));
+                    st128(dst + (po + pml - 16u), pb);
                 } else if (pml >= 8u) {
                     // exact-size copies without partial-word stores: the last piece overlaps the first
                     const uint32_t sh = pml - 8u;                   // 0..7: bytes [sh, sh + 8) of pa
@@ -93,11 +94,11 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     const uint32_t x = hi4 ? pa.y : pa.x, y = hi4 ? pa.z : pa.y, z = hi4 ? pa.w : pa.z;
                     const u32x2 a = {pa.x, pa.y};
                     const u32x2 b = {__builtin_amdgcn_alignbyte(y, x, sh & 3u), __builtin_amdgcn_alignbyte(z, y, sh & 3u)};
-                    __builtin_memcpy(o, &a, 8); __builtin_memcpy(o + sh, &b, 8);
+                    __builtin_memcpy(dst + po, &a, 8); __builtin_memcpy(dst + (po + sh), &b, 8);
                 } else {
                     const uint32_t sh = pml - 4u;                   // 0..3
                     const uint32_t a = pa.x, b = __builtin_amdgcn_alignbyte(pa.y, pa.x, sh);
-                    __builtin_memcpy(o, &a, 4); __builtin_memcpy(o + sh, &b, 4);
+                    __builtin_memcpy(dst + po, &a, 4); __builtin_memcpy(dst + (po + sh), &b, 4);
                 }
             }
             pml = 0;
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     // has been parsed.
                     const bool real = (R >> lane) & 1ull;
                     if (real) {
-                        const uint8_t *m = dst + (op + relv + lit - off);
-                        pa = ld128(m);
-                        if (ml >= 16u) pb = ld128(m + ml - 16u);
+                        const uint32_t mo = op + relv + lit - off;
+                        pa = ld128(dst + mo);
+                        if (ml >= 16u) pb = ld128(dst + (mo + ml - 16u));
                         pml = ml; po = op + relv + lit; pof = off;
                     }
                     DSTAMP(4);
