@@ -1022,7 +1022,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
 }  // namespace zlz4
 
 namespace {
-constexpr uint32_t kHcChunkBlocks = 4096;   // blocks per round (bounds the workspace)
+constexpr uint32_t kHcChunkBlocks = 8192;   // blocks per round (bounds the workspace: 3.5 GiB for 64 KiB blocks; 4096 / 8192 / 14043: 52.3 / 50.5 / 51.5 ms on configs[3])
 bool hc_small(uint32_t max_in_len) {
     // ZLZ4_HC_HBM_LINKS (A/B switch for profiles/): blocks <= 64 KiB through the variant that keeps the links in HBM
     static const bool force_hbm = zlz4_tune_env("ZLZ4_HC_HBM_LINKS") != nullptr;
@@ -1060,8 +1060,14 @@ extern "C" int zlz4_launch_compress_hc(hipStream_t stream, const uint8_t *d_in, 
     if (level < 2 || level > 12) return -8;
     if (ws_bytes < zlz4_hc_workspace_bytes(nblocks, max_in_len)) return -5;
     const uint32_t chunk = hc_chunk(nblocks, max_in_len);
-    if (level == 2)
-        return zlz4_launch_hc_mid(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, ws, chunk);
+    if (level == 2) {
+        // lz4mid needs its two tables only (128 KiB per block): the same workspace holds more blocks per launch, and one
+        // block per wavefront wants as many blocks in flight as the chip can hold
+        uint64_t mid_chunk = ws_bytes / zlz4_hc_mid_workspace_bytes(1);
+        if (mid_chunk > nblocks) mid_chunk = nblocks;
+        return zlz4_launch_hc_mid(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, ws,
+                                  (uint32_t)mid_chunk);
+    }
     const bool optimal = level >= 10;
     static const int32_t opt_nb[3] = {96, 512, 16384};
     static const uint32_t opt_target[3] = {64, 128, 4096};
