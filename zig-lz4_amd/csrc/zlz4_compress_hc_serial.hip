@@ -147,15 +147,35 @@ __global__ __launch_bounds__(64) void k_hc_mid_serial(const uint8_t *__restrict_
         const uint32_t mflimit = n - kMfLimit, matchlimit = n - kLastLiterals, ilimit = n - 8u;   // :698-700
         uint32_t ip = 0, anchor = 0, op = 0;
         bool failed = false;
+        // One lane walks the block and every probe is a chain of dependent HBM accesses (table entry -> candidate bytes,
+        // twice).  The chain is shortened without changing a single table state: both entries of the NEXT position are
+        // requested while the current one is examined (a probe without a match only writes h8[hh8] and h4[hh4], which
+        // the pre-read values are patched with), and both candidates' bytes are requested together.
+        bool have_pf = false;              // pf8 / pf4 are the entries of position ip as the serial loop would read them
+        uint32_t pf8 = 0, pf4 = 0, pfh8 = 0, pfh4 = 0;                            // (and pfh8 / pfh4 its two hashes)
         while (ip <= mflimit) {                                                   // :733
             const uint32_t ip_index = ip;
+            const uint32_t hh8 = have_pf ? pfh8 : hash_mid8(src + ip), hh4 = have_pf ? pfh4 : hash_mid4(src + ip);
+            const uint32_t pos8 = have_pf ? pf8 : h8[hh8];
+            const uint32_t pos4 = have_pf ? pf4 : h4[hh4];      // (nothing writes h4 before :828 when there is no long match)
+            // entries of the position a probe without a match goes to next (:937-938)
+            const uint32_t nip = ip + 1u + ((ip - anchor) >> 9);
+            const bool nvalid = nip <= mflimit;
+            uint32_t nh8 = 0, nh4 = 0, n8 = 0, n4 = 0;
+            if (nvalid) { nh8 = hash_mid8(src + nip); nh4 = hash_mid4(src + nip); n8 = h8[nh8]; n4 = h4[nh4]; }
+            const bool ok8 = pos8 > 0 && ip_index - pos8 <= kMaxDist && pos8 < ip;   // :744-748
+            const bool ok4 = pos4 > 0 && ip_index - pos4 <= kMaxDist && pos4 < ip;   // :832-836
+            // first 8 bytes of both candidates, in flight together (matchlimit >= ip + 7: mflimit = n - 12)
+            const uint64_t here = ld64(src + ip);
+            const uint64_t c8 = ok8 ? ld64(src + pos8) : ~here, c4 = ok4 ? ld64(src + pos4) : ~here;
             bool taken = false;
             {   // long match, 8-byte hash (:739-824)
-                const uint32_t hh = hash_mid8(src + ip);
-                const uint32_t pos8 = h8[hh];
-                h8[hh] = ip_index;                                                // :742
-                if (pos8 > 0 && ip_index - pos8 <= kMaxDist && pos8 < ip) {       // :744-748
-                    const uint32_t mlt = count_from(src, ip, pos8, matchlimit);   // :749
+                h8[hh8] = ip_index;                                               // :742
+                if (ok8) {
+                    const uint64_t x = here ^ c8;
+                    uint32_t mlt = x ? ((uint32_t)__builtin_ctzll(x) >> 3)
+                                     : 8u + count_from(src, ip + 8u, pos8 + 8u, matchlimit);   // :749
+                    if (mlt > matchlimit - ip) mlt = matchlimit - ip;             // (ip == mflimit: only 7 bytes may count)
                     if (mlt >= kMinMatch) {
                         if (ip + 1u <= ilimit) h8[hash_mid8(src + ip + 1u)] = ip_index + 1u;     // :767-769
                         if (ip + 2u <= ilimit) h8[hash_mid8(src + ip + 2u)] = ip_index + 2u;     // :770-772
@@ -166,13 +186,14 @@ __global__ __launch_bounds__(64) void k_hc_mid_serial(const uint8_t *__restrict_
                     }
                 }
             }
-            if (taken) continue;                                                  // :819
+            if (taken) { have_pf = false; continue; }                             // :819
             {   // short match, 4-byte hash (:827-934)
-                const uint32_t hh = hash_mid4(src + ip);
-                const uint32_t pos4 = h4[hh];
-                h4[hh] = ip_index;                                                // :830
-                if (pos4 > 0 && ip_index - pos4 <= kMaxDist && pos4 < ip) {       // :832-836
-                    uint32_t match_len = count_from(src, ip, pos4, matchlimit);   // :837
+                h4[hh4] = ip_index;                                               // :830
+                if (ok4) {
+                    const uint64_t x = here ^ c4;
+                    uint32_t match_len = x ? ((uint32_t)__builtin_ctzll(x) >> 3)
+                                           : 8u + count_from(src, ip + 8u, pos4 + 8u, matchlimit);   // :837
+                    if (match_len > matchlimit - ip) match_len = matchlimit - ip;
                     if (match_len >= kMinMatch) {
                         uint32_t match_dist = ip_index - pos4;
                         if (ip < mflimit) {                                       // :842
@@ -199,8 +220,13 @@ __global__ __launch_bounds__(64) void k_hc_mid_serial(const uint8_t *__restrict_
                     }
                 }
             }
-            if (taken) continue;                                                  // :929
-            ip += 1u + ((ip - anchor) >> 9);                                      // :937-938
+            if (taken) { have_pf = false; continue; }                             // :929
+            // no match: this probe wrote h8[hh8] = h4[hh4] = ip_index and nothing else
+            pf8 = nh8 == hh8 ? ip_index : n8;
+            pf4 = nh4 == hh4 ? ip_index : n4;
+            pfh8 = nh8; pfh4 = nh4;
+            have_pf = nvalid;
+            ip = nip;                                                             // :937-938
         }
         out = failed ? kErrOutputTooSmall : final_literals_lane(src, dst, oend, n, anchor, op);
     }
