@@ -156,7 +156,8 @@ int32_t zlz4_batch_decompress_safe(void *stream,
                                    uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
                                    int64_t *d_result, uint32_t nblocks);
 
-/* workspace for the HC path: bytes needed for `nblocks` blocks of at most `max_in_len` bytes */
+/* workspace for the HC path: bytes needed for `nblocks` blocks of at most `max_in_len` bytes (448 KiB per 64 KiB block
+ * up to 8192 blocks = 3.5 GiB, about 6 GiB at most for large blocks; longer batches are processed in rounds) */
 size_t  zlz4_batch_compress_hc_workspace(uint32_t nblocks, uint32_t max_in_len);
 int32_t zlz4_batch_compress_hc(void *stream,
                                const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
