@@ -59,6 +59,23 @@ def test_pure_arithmetic_entry_points(zl, oracle):
             assert e.name == name
 
 
+def test_hc_workspace_size_is_bounded_and_monotone(zl):
+    """zlz4_batch_compress_hc_workspace is host arithmetic: it grows with the batch up to the round size (8192 blocks of
+    64 KiB: 448 KiB each), stays near 6 GiB for large blocks, and never shrinks when the batch grows."""
+    per_block = 65536 * 6 + 65584                     # links + results, the level-10-12 price table
+    assert zl.batch_compress_hc_workspace(1, 65536) == per_block
+    assert zl.batch_compress_hc_workspace(8192, 65536) == 8192 * per_block
+    assert zl.batch_compress_hc_workspace(16384, 65536) == 8192 * per_block       # longer batches run in rounds
+    assert zl.batch_compress_hc_workspace(1 << 20, 65536) == 8192 * per_block
+    prev = 0
+    for nb in (1, 2, 100, 1000, 4096, 8192, 8193, 100000):
+        w = zl.batch_compress_hc_workspace(nb, 65536)
+        assert w >= prev
+        prev = w
+    big = zl.batch_compress_hc_workspace(1024, 4 << 20)
+    assert (4 << 20) * 12 <= big <= (6 << 30) + (64 << 20)
+
+
 def test_error_names_follow_the_reference(zl):
     names = {-1: "OutputTooSmall", -2: "InputTooLarge", -3: "CorruptedData", -4: "DecompressionFailed",
              -5: "InvalidState", -6: "AllocationFailed", -101: "Generic", -111: "DstMaxSizeTooSmall",
