@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""Build-time audit of the decoder's hand-issued window prefetch (zig-lz4_amd/csrc/zlz4_decompress.hip).
+"""Build-time audit of the decoder's hand-issued loads (zig-lz4_amd/csrc/zlz4_decompress.hip).
 
-k_decompress_safe issues `global_load_dword` from an asm statement with a plain "=v" output and waits for it in a
-separate asm `s_waitcnt vmcnt(0)` (the compiler's own vmcnt bookkeeping would drain the queue earlier).  hipcc does not
-know the register is in flight: a copy, spill or reuse of that VGPR between the two statements would read stale data
-silently (cdna_hip_programming.md section 5.7 item 1).  This script compiles the file to assembly and checks, for every
-such load, that no instruction on any control-flow path from it to the next asm `s_waitcnt vmcnt(0)` names the destination
-register.  Run by `make check-asm` and tests/test_capi.py; re-run it -- and
-the decoder parity tests on the GPU -- after any toolchain or flag change.
+k_decompress_safe issues three kinds of loads from asm statements with plain register outputs and waits for them in
+separate asm `s_waitcnt` statements (the compiler's own vmcnt bookkeeping would drain the queue at the first use):
+  * the window load (`global_load_dword`) and the match loads (`global_load_dwordx4`): awaited by the batch's
+    `s_waitcnt vmcnt(1)` -- everything but the youngest operation -- or by a `vmcnt(0)`;
+  * the far-ahead touch (`global_load_ubyte`), issued as the LAST vector-memory operation of a batch: it is the one
+    operation a `vmcnt(1)` leaves in flight, so it is only covered by a `vmcnt(0)`, or by a `vmcnt(1)` that comes after
+    the NEXT touch has been issued.
+hipcc does not know these registers are in flight: a copy, spill or reuse of one of them between issue and wait would
+read stale data silently (cdna_hip_programming.md section 5.7 item 1).  This script compiles the file to assembly and
+checks, for every such load, that no instruction outside the asm statements names a destination register on any
+control-flow path from the load to the wait that covers it.  Run by `make check-asm` and tests/test_capi.py; re-run it
+-- and the decoder parity tests on the GPU -- after any toolchain or flag change.
 """
 import os
 import re
@@ -55,40 +60,55 @@ def audit(asm_text):
             asm_region[i] = inside
             if ";;#ASMEND" in lines[i]:
                 inside = False
+        load_re = re.compile(r"^global_load_(dword|dwordx4|ubyte)\s+(v\d+|v\[\d+:\d+\])")
         for i in range(k0, k1 + 1):
             t = lines[i].strip()
-            if not (asm_region[i] and t.startswith("global_load_dword ")):
+            m0 = load_re.match(t) if asm_region[i] else None
+            if not m0:
                 continue
-            dest = int(re.search(r"global_load_dword\s+v(\d+)", t).group(1))
+            kind = m0.group(1)
+            dest = regs_in(m0.group(2))
             checked += 1
-            seen, stack, waits = set(), [i + 1], 0
+            # state: (line, a newer touch has been issued since this load)
+            seen, stack, waits = set(), [(i + 1, False)], 0
             while stack:
-                j = stack.pop()
+                j, newer = stack.pop()
                 while j <= k1:
-                    if j in seen:
+                    if (j, newer) in seen:
                         break
-                    seen.add(j)
+                    seen.add((j, newer))
                     t = lines[j].strip().split(";")[0].strip() if not lines[j].strip().startswith(";;") else ""
                     if not t or t.startswith((".", "//")) or t.endswith(":"):
                         j += 1
                         continue
-                    if asm_region[j] and t.startswith("s_waitcnt") and "vmcnt(0)" in t:
-                        waits += 1
-                        break                                   # this path is covered
+                    if asm_region[j] and t.startswith("s_waitcnt"):
+                        if "vmcnt(0)" in t or ("vmcnt(1)" in t and (kind != "ubyte" or newer)):
+                            waits += 1
+                            break                               # this path is covered
+                        j += 1
+                        continue
                     if t.startswith("s_endpgm"):
+                        problems.append("the load at line %d reaches s_endpgm without a covering wait" % (i + 1))
                         break
-                    if not (asm_region[j] and t.startswith("global_load_dword ")) and dest in regs_in(t):
-                        problems.append("v%d (in flight since line %d) is touched at line %d: %s" % (dest, i + 1, j + 1, t))
+                    if asm_region[j] and load_re.match(t):
+                        if t.startswith("global_load_ubyte"):
+                            newer = True                        # (writes the touch register again: still asm, still fine)
+                        elif dest & regs_in(load_re.match(t).group(2)):
+                            problems.append("v%s (in flight since line %d) is loaded again at line %d before its wait" % (sorted(dest), i + 1, j + 1))
+                        j += 1
+                        continue
+                    if dest & regs_in(t):
+                        problems.append("v%s (in flight since line %d) is touched at line %d: %s" % (sorted(dest), i + 1, j + 1, t))
                     m = re.match(r"^(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", t)
                     if m:
                         tgt = label_at.get(m.group(2))
                         if tgt is not None:
-                            stack.append(tgt)
+                            stack.append((tgt, newer))
                         if m.group(1) == "s_branch":
                             break
                     j += 1
             if waits == 0:
-                problems.append("no asm s_waitcnt vmcnt(0) reachable from the load at line %d" % (i + 1))
+                problems.append("no covering asm s_waitcnt reachable from the load at line %d" % (i + 1))
     return checked, problems
 
 

@@ -137,16 +137,18 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                   asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(woff(p)), "s"(src) : "memory");
                   return r;
               };
-              uint32_t xbase = ip;
+              // The compressed stream is read once, front to back: every window load is a miss all the way to HBM, and
+              // with one in-order vmcnt queue a wait for the match data is a wait for that miss too.  So one byte of the
+              // stream 1 KiB ahead is touched per batch, as the LAST vector-memory operation of the batch: the batch's
+              // one wait is `vmcnt(1)` -- everything but the youngest operation, i.e. everything but the touch, which
+              // gets a second batch to come back -- and the window loads behind it find their lines in the cache.
+              // The match loads are hand-issued for the same reason (the compiler, tracking them, would drain the
+              // queue before their first use); pa / pb / X2 / tdummy must not be touched between issue and wait.
+              uint32_t xbase = ip, tdummy = 0;
               uint32_t X0 = ld32(src + woff(xbase)), X1 = ld32(src + woff(xbase + 64u));
               uint32_t X2 = wload_async(xbase + 128u);
               asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(X0), "+v"(X1));
               for (;;) {
-                {   // branch-free shift, one window load per batch
-                    const bool adv = ip - xbase >= 64u;
-                    X0 = adv ? X1 : X0; X1 = adv ? X2 : X1; xbase += adv ? 64u : 0u;
-                    X2 = wload_async(xbase + 128u);
-                }
                 const uint32_t xi = ip - xbase + lane;
                 const uint32_t xa = shfl(X0, xi & 63u), xb = shfl(X1, xi & 63u);
                 const uint32_t w4 = xi < 64u ? xa : xb;             // lane i: src[ip + i .. ip + i + 3]
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 DSTAMP(2);
                 // The one wait of a batch: the window load issued at the top of this iteration and the match loads of
                 // the previous batch have had the whole parse / walk / scan to arrive.
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2));
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(tdummy));
                 if (R == 0) break;                                  // the single-sequence paths take this one
                 DSTAMP_ADD(8, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
                 if (kWrite) {
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     const bool real = (R >> lane) & 1ull;
                     if (real) {
                         const uint32_t mo = op + relv + lit - off;
-                        pa = ld128(dst + mo);
-                        if (ml >= 16u) pb = ld128(dst + (mo + ml - 16u));
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pa) : "v"(mo), "s"(dst) : "memory");
+                        if (ml >= 16u)
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pb) : "v"(mo + ml - 16u), "s"(dst) : "memory");
                         pml = ml; po = op + relv + lit; pof = off;
                     }
                     DSTAMP(4);
@@ -290,7 +293,16 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 op += T;
                 ip += pos;
                 if ((uint64_t)ip + 68u > iend) break;
+                {   // branch-free shift, one window load per batch, then the touch
+                    const bool adv = ip - xbase >= 64u;
+                    X0 = adv ? X1 : X0; X1 = adv ? X2 : X1; xbase += adv ? 64u : 0u;
+                    X2 = wload_async(xbase + 128u);
+                    const uint32_t ta = xbase + 128u + 1024u;
+                    const uint32_t toff = ta < iend ? ta : iend - 1u;
+                    asm volatile("global_load_ubyte %0, %1, %2" : "+v"(tdummy) : "v"(toff), "s"(src) : "memory");
+                }
               }
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(tdummy));
               if (ip >= iend) { flush_pending(); break; }
             }
             flush_pending();
