@@ -50,11 +50,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 
 // kWrite == false: size pass (no stores) -- used by the frame decoder to learn every block's
 // decompressed size before placing the blocks (lz4f.decompressFrame accumulates dstPos serially).
-template <bool kWrite>
+// kLaneCopy: short matches are moved four bytes per lane (batches that fill the chip); false = 16 bytes per sequence lane
+// for every match (few blocks: the shorter latency chain)
+template <bool kWrite, bool kLaneCopy = false>
 __global__ __launch_bounds__(256) void k_decompress_safe(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
     const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks) {
+    constexpr uint32_t short_max = kLaneCopy ? 32u : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t blk = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (blk >= nblocks) return;
@@ -78,8 +81,20 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
         // pof = match offset, pa / pb = first and last piece (16, 8 or 4 bytes each).
         uint32_t pml = 0, po = 0, pof = 0;
         u32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+        // Matches of <= 32 bytes (nearly all of a batch) are moved four bytes per lane, eight lanes per sequence: ONE dword
+        // load and ONE dword store serve eight sequences, where a 16-byte move per sequence lane costs the CU's address
+        // path four times the cycles per instruction for an eighth of the lanes.  pd = the lane's piece, pdo = where it
+        // goes (kNone = nothing pending); up to three rounds of eight sequences per batch.
+        constexpr uint32_t kNone = 0xFFFFFFFFu;
+        uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pdo0 = kNone, pdo1 = kNone, pdo2 = kNone;
         auto flush_pending = [&]() {
             if (!kWrite) return;
+            if constexpr (kLaneCopy) {
+                if (pdo0 != kNone) __builtin_memcpy(dst + pdo0, &pd0, 4);
+                if (pdo1 != kNone) __builtin_memcpy(dst + pdo1, &pd1, 4);
+                if (pdo2 != kNone) __builtin_memcpy(dst + pdo2, &pd2, 4);
+                pdo0 = pdo1 = pdo2 = kNone;
+            }
             if (pml != 0) {
                 // (every address is dst + a 32-bit offset: the uniform base stays in scalar registers and no lane
                 //  spends vector instructions on 64-bit pointer arithmetic)
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 DSTAMP(2);
                 // The one wait of a batch: the window load issued at the top of this iteration and the match loads of
                 // the previous batch have had the whole parse / walk / scan to arrive.
-                asm volatile("s_waitcnt vmcnt(1)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(tdummy));
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(tdummy));
                 if (R == 0) break;                                  // the single-sequence paths take this one
                 DSTAMP_ADD(8, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
                 if (kWrite) {
@@ -281,12 +296,45 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     // 16-byte loads per sequence lane; the data is stored by flush_pending() after the next batch
                     // has been parsed.
                     const bool real = (R >> lane) & 1ull;
-                    if (real) {
-                        const uint32_t mo = op + relv + lit - off;
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pa) : "v"(mo), "s"(dst) : "memory");
-                        if (ml >= 16u)
-                            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pb) : "v"(mo + ml - 16u), "s"(dst) : "memory");
-                        pml = ml; po = op + relv + lit; pof = off;
+                    const uint32_t po_t = op + relv + lit, mo_t = po_t - off;       // (off <= 65535, ml <= 273)
+                    // short_max = 32 when the chip is full (the address path is what bounds the kernel then), 0 with few
+                    // blocks (one wavefront per SIMD: the permutes are four more dependent steps of a latency chain, and
+                    // 16 bytes per sequence lane is the shorter chain: 38.3 against 43.4 ms on 1024 x 4 MiB)
+                    [[maybe_unused]] const bool shortm = real && ml <= short_max;
+                    if (!kLaneCopy || ballot(real && ml > short_max)) {   // long matches: 16-byte pieces per sequence lane
+                        if (real && ml > short_max) {
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pa) : "v"(mo_t), "s"(dst) : "memory");
+                            if (ml >= 16u)
+                                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pb) : "v"(mo_t + ml - 16u), "s"(dst) : "memory");
+                            pml = ml; po = po_t; pof = off;
+                        }
+                    }
+                    if constexpr (kLaneCopy) {
+                        const uint64_t S = ballot(shortm);
+                        const uint32_t ns = (uint32_t)__popcll(S);                       // <= 21 sequences per batch
+                        const uint32_t rk = (uint32_t)__popcll(S & ((1ull << lane) - 1ull));
+                        const uint32_t lead = (lane & ~7u) << 2, k4 = (lane & 7u) * 4u, grp = lane >> 3;
+                        // one round: the sequences of rank g0 .. g0 + 7 send (source, destination, length) to the first lane
+                        // of their group of eight (ds_permute; everybody else sends to lane 63, which leads no group), the
+                        // group reads them back, lane k of the group takes the piece at min(4k, ml - 4)
+                        auto round = [&](uint32_t g0, uint32_t &pd, uint32_t &pdo) {
+                            const uint32_t rel = rk - g0;
+                            const uint32_t dest = (shortm && rel < 8u ? rel * 8u : 63u) << 2;
+                            const uint32_t s_po = (uint32_t)__builtin_amdgcn_ds_permute((int)dest, (int)po_t);
+                            const uint32_t s_om = (uint32_t)__builtin_amdgcn_ds_permute((int)dest, (int)(off | (ml << 16)));
+                            const uint32_t g_po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)s_po);
+                            const uint32_t g_om = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)s_om);
+                            const uint32_t g_ml = g_om >> 16, g_mo = g_po - (g_om & 0xFFFFu);
+                            const bool act = g0 + grp < ns && k4 < g_ml;
+                            const uint32_t pk = k4 + 4u <= g_ml ? k4 : g_ml - 4u;       // the last piece overlaps the one before
+                            if (act) {
+                                asm volatile("global_load_dword %0, %1, %2" : "+v"(pd) : "v"(g_mo + pk), "s"(dst) : "memory");
+                                pdo = g_po + pk;
+                            }
+                        };
+                        round(0u, pd0, pdo0);
+                        if (ns > 8u) round(8u, pd1, pdo1);
+                        if (ns > 16u) round(16u, pd2, pdo2);
                     }
                     DSTAMP(4);
                 }
@@ -302,7 +350,7 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     asm volatile("global_load_ubyte %0, %1, %2" : "+v"(tdummy) : "v"(toff), "s"(src) : "memory");
                 }
               }
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(tdummy));
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(tdummy));
               if (ip >= iend) { flush_pending(); break; }
             }
             flush_pending();
@@ -559,6 +607,7 @@ __global__ __launch_bounds__(64) void k_decompress_lane(
 
 }  // namespace zlz4
 
+constexpr uint32_t kLaneCopyMinBlocks = 6144;   // (crossover measured between 4096 and 8192 blocks; the chip holds 8192 wavefronts)
 extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
                                            const uint32_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                                            const uint32_t *d_out_cap, int64_t *d_result, uint32_t nblocks) {
@@ -584,8 +633,15 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
     // experiment knob: dynamic LDS per workgroup only to limit the number of resident wavefronts per CU
     static const uint32_t dyn_lds = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_LDS"); return e ? (uint32_t)atoll(e) : 0u; }();
-    hipLaunchKernelGGL(zlz4::k_decompress_safe<true>, dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in, d_in_off,
-                       d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+    // short matches four bytes per lane once the batch fills the chip (see the kernel); ZLZ4_DECOMP_SHORT forces 0 / 32
+    static const int short_env = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_SHORT"); return e ? atoi(e) : -1; }();
+    const uint32_t short_max = short_env >= 0 ? (uint32_t)short_env : (nblocks >= kLaneCopyMinBlocks ? 32u : 0u);
+    if (short_max)
+        hipLaunchKernelGGL((zlz4::k_decompress_safe<true, true>), dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in,
+                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+    else
+        hipLaunchKernelGGL((zlz4::k_decompress_safe<true, false>), dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in,
+                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
 
@@ -596,7 +652,7 @@ extern "C" int zlz4_launch_decompress_sizes(hipStream_t stream, const uint8_t *d
     if (nblocks == 0) return 0;
     const uint32_t waves_per_wg = 4;
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
-    hipLaunchKernelGGL(zlz4::k_decompress_safe<false>, dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
+    hipLaunchKernelGGL((zlz4::k_decompress_safe<false, false>), dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
                        d_in_len, (uint8_t *)nullptr, d_out_off, d_out_cap, d_result, nblocks);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
