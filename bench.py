@@ -351,12 +351,14 @@ def main():
         comp_gibs = None if decomp_only else total_n / (tc_ms * 1e-3) / GIB
         dec_gibs = total_n / (td_ms * 1e-3) / GIB
         hc_kernels = ("zlz4::k_hc_mid_serial" if args.level <= 2 else
-                      "HC pipeline: k_hc_build_links + k_hc_seg_search<4> + k_hc_parse_emit (rounds of 2048 blocks, emit beside the next round)" if args.level <= 9 else
-                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse (rounds of 4096 blocks)")
+                      "HC pipeline: k_hc_build_links + k_hc_seg_search<4> + k_hc_parse_emit (rounds of 4096 blocks, emit beside the next round)" if args.level <= 9 else
+                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse (rounds of 8192 blocks)")
+        # the decoder has two builds: lane-per-dword match copies for batches that fill the chip, 16 bytes per sequence lane below
+        dec_kernel = "zlz4::k_decompress_safe<true, %s>" % ("true" if nblocks >= 6144 else "false")
         kc = {"cfg2": "zlz4::k_compress_fast<uint16_t>", "cfg4": hc_kernels,
               "cfg5": "zlz4::k_compress_fast<uint32_t>", "cfg3": None}[args.workload]
         if decomp_only:
-            dom, dom_ms = "zlz4::k_decompress_safe<true>", td_ms
+            dom, dom_ms = dec_kernel, td_ms
         else:
             dom, dom_ms = kc, tc_ms
         # HBM traffic from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE collected in separate
@@ -386,7 +388,7 @@ def main():
                          "traffic_source": (None if not traffic else
                                             "from profile, not measured in this run: " + str(traffic.get("source"))),
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms},
-            "roofline_decompress": {"bound": "hbm", "kernel": "zlz4::k_decompress_safe<true>",
+            "roofline_decompress": {"bound": "hbm", "kernel": dec_kernel,
                                     "achieved": algo / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": algo / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "traffic": traffic.get("decompress"), "avg_launch_ms": td_ms},
