@@ -130,6 +130,50 @@ def cpu_baseline(sample_blocks, block_size, slot, hc_level=None):
     }
 
 
+def launch_ranks(n):
+    """One fresh child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them),
+    same command line.  Rank 0's stdout (the JSON line) is forwarded; a failing rank ends the others and the exit
+    code is non-zero."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    buf = []
+    t = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    rc, deadline = 0, time.time() + 3600
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            # a rank that died leaves the others in a barrier: end them (exact PIDs, nothing by pattern)
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            for r, c in bad:
+                log("rank %d exited with %d" % (r, c))
+            rc = 1
+            break
+        time.sleep(0.2)
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0 and rc == 0:
+            log("rank %d exited with %d" % (r, c))
+            rc = 1
+    t.join(timeout=10)
+    out0 = buf[0] if buf else b""
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +186,11 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=0)
     ap.add_argument("--level", type=int, default=9, help="compressHC level for cfg4 (2..12)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here.  Nothing above has touched the GPU
+        # (importing torch does not), and this process never does: it only waits and passes rank 0's JSON line on.
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -366,7 +415,10 @@ def main():
         traffic = {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tj.get("%s/%s/%d" % (args.workload, args.dist, nblocks), {})
+            tkey = "%s/%s/%d" % (args.workload, args.dist, nblocks)
+            if args.workload == "cfg4":
+                tkey += "/L%d" % args.level          # the HC levels run different kernels
+            traffic = tj.get(tkey, {})
         except Exception:
             pass
         algo = total_n + total_c

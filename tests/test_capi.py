@@ -126,3 +126,31 @@ def test_decoder_hand_issued_loads_are_not_touched_before_their_wait():
         pytest.skip("no hipcc")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_decoder_asm.py")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_zig_facade_declares_the_reference_names():
+    """zig/root.zig cannot be compiled here (no zig toolchain), so at least its text is checked: every public name of
+    src/root.zig:1-57 and the lz4f names a drop-in caller uses (src/lz4f.zig:31-57 `Error` with all 23 members and
+    `isError`, :64-79 `BlockSizeID.toBlockSize`, :100-111 `FrameInfo.frameType`) are declared, and every extern
+    function it binds is exported by the library."""
+    import re
+    txt = open(os.path.join(ROOT, "zig-lz4_amd", "zig", "root.zig")).read()
+    for name in ("compressBound", "compressDefault", "compressFast", "decompressSafe", "compressHC", "compressHCExtState",
+                 "MINMATCH", "LZ4_MAX_INPUT_SIZE", "LZ4_DISTANCE_MAX", "LZ4HC_CLEVEL_MIN", "LZ4HC_CLEVEL_DEFAULT",
+                 "LZ4HC_CLEVEL_MAX"):
+        assert re.search(r"pub (const|fn) %s\b" % name, txt), name
+    m = re.search(r"pub const Error = error\{(.*?)\};", txt[txt.index("pub const lz4f = struct"):], re.S)
+    assert m, "lz4f.Error"
+    members = set(re.findall(r"\w+", m.group(1)))
+    ref = """Generic MaxBlockSizeInvalid BlockModeInvalid ParameterInvalid CompressionLevelInvalid HeaderVersionWrong
+             BlockChecksumInvalid ReservedFlagSet AllocationFailed SrcSizeTooLarge DstMaxSizeTooSmall FrameHeaderIncomplete
+             FrameTypeUnknown FrameSizeWrong SrcPtrWrong DecompressionFailed HeaderChecksumInvalid ContentChecksumInvalid
+             FrameDecodingAlreadyStarted CompressionStateUninitialized ParameterNull MaxCode OutOfMemory""".split()
+    assert len(ref) == 23 and not [r for r in ref if r not in members], [r for r in ref if r not in members]
+    for frag in ("pub fn isError(code: usize) bool", "pub fn toBlockSize(self: BlockSizeID) Error!usize",
+                 "frameType: FrameType = .frame", "pub const FrameType = enum(u1)"):
+        assert frag in txt, frag
+    import zig_lz4_amd
+    L = zig_lz4_amd.lib()
+    for fn in set(re.findall(r"extern fn (zlz4f?_\w+)\(", txt)):
+        assert hasattr(L, fn), "root.zig binds %s, which the library does not export" % fn

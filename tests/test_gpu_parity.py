@@ -240,7 +240,8 @@ def test_batch_max_in_len_understated(zl, oracle, gpu):
     """A block longer than the call's max_in_len is refused (InvalidState) and its neighbours are unaffected."""
     import torch
     items = [bytes(dg.text_bytes(3000, 1)), bytes(dg.text_bytes(70000, 2)), bytes(dg.text_bytes(5000, 3)), bytes(dg.text_bytes(66000, 4))]
-    for kind, level, lie in (("fast", 0, 8192), ("hc", 9, 8192), ("hc", 12, 8192), ("hc", 9, 65536), ("fast", 0, 65536)):
+    for kind, level, lie in (("fast", 0, 8192), ("hc", 9, 8192), ("hc", 12, 8192), ("hc", 2, 8192), ("hc", 9, 65536), ("hc", 2, 65536),
+                             ("fast", 0, 65536)):
         buf, offs, lens = gh._pack(items)
         caps = np.array([zl.compressBound(len(b)) for b in items], dtype=np.int64)
         out_offs = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16 + 64)[:-1]]).astype(np.int64)

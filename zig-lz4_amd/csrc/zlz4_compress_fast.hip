@@ -97,7 +97,13 @@ __device__ __forceinline__ uint32_t extend_match(const uint8_t *__restrict__ src
     }
 }
 
-template <typename T>   // T = uint16_t when every stored position fits 16 bits, else uint32_t
+// T = uint16_t when every stored position fits 16 bits, else uint32_t.
+// kTag: every table entry carries 8 more bits of the hashed sequence's product (bits 12..19; the index is bits 20..31),
+// so a probe whose candidate cannot pass the 4-byte test of :348 is settled from LDS and never gathers the candidate's
+// bytes from memory (on text more than half of all candidates are false: 4096 slots, 64 Ki positions).  A tag mismatch
+// implies a 4-byte mismatch, so no decision changes.  1 = a separate u8 array beside the u16 table (12 KiB per
+// wavefront), 2 = packed into bits 24..31 of a u32 entry (positions < 2^24), 0 = none.
+template <typename T, int kTag>
 __global__ __launch_bounds__(256) void k_compress_fast(
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
@@ -113,7 +119,12 @@ __global__ __launch_bounds__(256) void k_compress_fast(
     // (typed as address space 3: a generic `volatile T *` would compile to FLAT loads/stores with a full
     //  `s_waitcnt vmcnt(0)` each, i.e. every table access would also wait for the global gathers in flight)
     typedef __attribute__((address_space(3))) volatile T lds_entry;
+    typedef __attribute__((address_space(3))) volatile uint8_t lds_tag;
     lds_entry *table = (lds_entry *)lds_raw + wave_in_wg * 4096u;
+    // kTag == 1: the tag arrays follow the tables of all wavefronts of the workgroup (never initialised: an empty slot
+    // is recognised by its position 0 before its tag is looked at)
+    lds_tag *tags = (lds_tag *)lds_raw + (blockDim.x >> 6) * 4096u * (uint32_t)sizeof(T) + wave_in_wg * 4096u;
+    constexpr uint32_t kPosMask = kTag == 2 ? 0x00FFFFFFu : 0xFFFFFFFFu;
 
     const uint8_t *src = d_in + d_in_off[blk];
     uint8_t *dst = d_out + d_out_off[blk];
@@ -181,22 +192,30 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const uint32_t pos = A + lane;
                 const bool wr = has_ins || lane > 0;                    // position 0 is never inserted (Q1)
                 const u32x4 fwd = (pf_anchor == A) ? fwd_pf : ld128(src + pos);
-                const uint32_t h = hash4(fwd.x);                        // :341
+                const uint32_t prod = fwd.x * kHashMul;
+                const uint32_t h = prod >> 20;                          // :341
+                const uint32_t tg = (prod >> 12) & 0xFFu;
+                const uint32_t mine = kTag == 2 ? (pos | (tg << 24)) : (uint32_t)(T)pos;     // my table entry
                 STAMP(1);
                 STAMP_COUNT(16);
-                uint32_t old = 0, rb = 0;
-                if (wr) old = table[h];                                 // :342
+                uint32_t old_e = 0, rb = 0, told = tg;
+                if (wr) {
+                    old_e = table[h];                                   // :342
+                    if (kTag == 1) told = tags[h];
+                }
+                if (kTag == 2) told = old_e >> 24;
+                const uint32_t old = old_e & kPosMask;
                 // pre-window candidates: the old table value passes `match > 0`, `match < ip` (always) and
                 // the distance test (:345-347); its bytes are gathered once for the whole window.  The gather is
                 // issued right away so that its latency overlaps the speculative put / read-back below.
-                const bool old_ok = wr && old > 0 && (old + kMaxDist >= pos);
+                const bool old_ok = wr && old > 0 && (old + kMaxDist >= pos) && (kTag == 0 || told == tg);
                 u32x4 cold = {0, 0, 0, 0};
                 if (old_ok) cold = ld128(src + old);
                 STAMP(3);
-                if (wr) table[h] = (T)pos;                              // :350 (speculative)
+                if (wr) table[h] = (T)mine;                             // :350 (speculative)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (wr) rb = table[h];
-                uint64_t losers = ballot(wr && rb != (uint32_t)(T)pos);
+                uint64_t losers = ballot(wr && rb != mine);
                 uint64_t grp = lane_bit;
                 while (losers) {                                        // one round per duplicate-hash group
                     const uint32_t l = first_lane(losers);
@@ -464,9 +483,12 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const uint64_t ins = wrmask & ~covered_now() & (f_end >= 64u ? ~0ull : (1ull << f_end) - 1ull);
                 if (failed) break;
                 // ---- leave the table as the serial loop would have ----
-                if (wr && !(ins & lane_bit)) table[h] = (T)old;
+                if (wr && !(ins & lane_bit)) table[h] = (T)old_e;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if ((ins & lane_bit) && (grp & ins & ~lanes_below & ~lane_bit) == 0) table[h] = (T)pos;
+                if ((ins & lane_bit) && (grp & ins & ~lanes_below & ~lane_bit) == 0) {
+                    table[h] = (T)mine;
+                    if (kTag == 1) tags[h] = (uint8_t)tg;               // (the speculative put left the old tag in place)
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 STAMP(5);
                 moved = anchor != A;
@@ -524,18 +546,24 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 u32x4 fwd = {0, 0, 0, 0};
                 if (have16) fwd = ld128(src + pos);
                 else if (active) fwd.x = ld32(src + pos);
-                const uint32_t h = hash4(fwd.x);                        // :341
+                const uint32_t prod = fwd.x * kHashMul;
+                const uint32_t h = prod >> 20;                          // :341
+                const uint32_t tg = (prod >> 12) & 0xFFu;
+                const uint32_t mine = kTag == 2 ? (pos | (tg << 24)) : (uint32_t)(T)pos;
 
                 // table read / speculative put / read-back
-                uint32_t old = 0, rb = 0;
+                uint32_t old_e = 0, rb = 0, told = tg;
                 if (active) {
-                    old = table[h];                                     // :342
-                    table[h] = (T)pos;                                  // :350 (speculative)
+                    old_e = table[h];                                   // :342
+                    if (kTag == 1) told = tags[h];
+                    table[h] = (T)mine;                                 // :350 (speculative)
                 }
+                if (kTag == 2) told = old_e >> 24;
+                const uint32_t old = old_e & kPosMask;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (active) rb = table[h];
                 // duplicate-hash groups inside the batch
-                uint64_t losers = ballot(active && rb != (uint32_t)(T)pos);
+                uint64_t losers = ballot(active && rb != mine);
                 uint64_t grp = lane_bit;
                 int32_t pred = -1;
                 while (losers) {
@@ -553,7 +581,8 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const uint32_t cand = pred >= 0 ? pred_pos : old;
 
                 // the four validity tests of :345-348
-                bool valid = is_probe && active && cand > 0 && cand < pos && (cand + kMaxDist >= pos);
+                bool valid = is_probe && active && cand > 0 && cand < pos && (cand + kMaxDist >= pos) &&
+                             (kTag == 0 || pred >= 0 || told == tg);
                 u32x4 cnd = {0, 0, 0, 0};
                 if (valid) {
                     if (have16) cnd = ld128(src + cand); else cnd.x = ld32(src + cand);
@@ -566,10 +595,13 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     const uint32_t wl = first_lane(valid_mask);
                     // lanes after the winner never ran in the serial loop: undo their puts, then
                     // re-commit the last lane <= wl of every duplicate group
-                    if (active && lane > wl) table[h] = (T)old;
+                    if (active && lane > wl) table[h] = (T)old_e;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     const uint64_t upto = (2ull << wl) - 1ull;   // lanes 0..wl
-                    if (active && lane <= wl && ((grp & upto & ~lanes_below & ~lane_bit) == 0)) table[h] = (T)pos;
+                    if (active && lane <= wl && ((grp & upto & ~lanes_below & ~lane_bit) == 0)) {
+                        table[h] = (T)mine;
+                        if (kTag == 1) tags[h] = (uint8_t)tg;
+                    }
                     // local extension: bytes 4..15 of the two 16-byte reads (:401-413)
                     uint32_t loc = 0;
                     bool loc_done = false;
@@ -592,7 +624,10 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 }
                 if (bail_mask) { bailed = true; break; }                // :335-338 -> finishCompression
                 // no match in 64 probes: all puts stand; fix duplicate groups so the last lane's position is stored
-                if (active && grp != lane_bit && ((grp & ~lanes_below & ~lane_bit) == 0)) table[h] = (T)pos;
+                if (active && ((grp & ~lanes_below & ~lane_bit) == 0)) {
+                    if (grp != lane_bit) table[h] = (T)mine;
+                    if (kTag == 1) tags[h] = (uint8_t)tg;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 ub += 64;
             }
@@ -644,20 +679,28 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
     static const uint32_t lds_pad = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
     // every position stored in the table is < srcSize - 12, so 16-bit entries are exact up to 65547-byte blocks
     static const uint32_t tune_wpw = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_WPW"); return e ? (uint32_t)atoi(e) : 0u; }();
+    // tags (see k_compress_fast): free in a u32 entry (configs[4] shape 132.6 -> 125.9 ms); beside the u16 table they cost
+    // LDS, 20 -> 13 wavefronts per CU, and lose (configs[1] 42.8 -> 54.0 ms; profiles/r03_fast_compress_tags.md), so
+    // the u16 build carries them only when asked to (tuning build: ZLZ4_TUNE_TAG=1)
+    static const int tune_tag = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_TAG"); return e ? atoi(e) : -1; }();
+#define ZLZ4_LAUNCH_FAST(T, TAG, WPW, LDS)                                                                            \
+    hipLaunchKernelGGL((zlz4::k_compress_fast<T, TAG>), dim3((nblocks + (WPW) - 1) / (WPW)), dim3(64 * (WPW)), (LDS),    \
+                       stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, acceleration,  \
+                       max_in_len)
     if (max_in_len <= 65536u + 11u) {
-        // 8 KiB of LDS per wavefront -> 20 wavefronts per CU whatever the workgroup size; one-wave workgroups measured
-        // 5 % faster than four-wave ones on MI355X (44.1 / 45.0 / 46.6 ms for 1 / 2 / 4 on configs[1]): a finished
-        // block frees its slot at once instead of waiting for the slowest of four
+        // 8 KiB of table (+ 4 KiB of tags) per wavefront in LDS -> 20 (13) wavefronts per CU whatever the workgroup size;
+        // one-wave workgroups measured 5 % faster than four-wave ones on MI355X (44.1 / 45.0 / 46.6 ms for 1 / 2 / 4 on
+        // configs[1]): a finished block frees its slot at once instead of waiting for the slowest of four
         const uint32_t wpw = (tune_wpw == 2 || tune_wpw == 4) ? tune_wpw : 1;
-        hipLaunchKernelGGL(zlz4::k_compress_fast<uint16_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
-                           wpw * 4096 * sizeof(uint16_t) + lds_pad, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration, max_in_len);
+        if (tune_tag > 0) ZLZ4_LAUNCH_FAST(uint16_t, 1, wpw, wpw * (4096 * sizeof(uint16_t) + 4096) + lds_pad);
+        else ZLZ4_LAUNCH_FAST(uint16_t, 0, wpw, wpw * 4096 * sizeof(uint16_t) + lds_pad);
     } else {
         const uint32_t wpw = (tune_wpw == 2) ? 2 : 1;   // 16 KiB of LDS per wavefront -> 10 wavefronts per CU
-        hipLaunchKernelGGL(zlz4::k_compress_fast<uint32_t>, dim3((nblocks + wpw - 1) / wpw), dim3(64 * wpw),
-                           wpw * 4096 * sizeof(uint32_t), stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
-                           d_out_cap, d_result, nblocks, acceleration, max_in_len);
+        // positions below 2^24 leave the top byte of a u32 entry to the tag
+        if (tune_tag != 0 && max_in_len <= (1u << 24)) ZLZ4_LAUNCH_FAST(uint32_t, 2, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
+        else ZLZ4_LAUNCH_FAST(uint32_t, 0, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
     }
+#undef ZLZ4_LAUNCH_FAST
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
 

@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
 }  // namespace zlz4
 
 extern "C" int zlz4_launch_hc_mid(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *, const uint64_t *,
-                                  const uint32_t *, int64_t *, uint32_t, void *, uint32_t);
+                                  const uint32_t *, int64_t *, uint32_t, void *, uint32_t, uint32_t);
 extern "C" int zlz4_launch_hc_opt_parse(hipStream_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *,
                                         const uint64_t *, const uint32_t *, int64_t *, const void *, uint64_t, int, void *,
                                         uint32_t, uint32_t, uint32_t, uint32_t);
@@ -912,13 +912,26 @@ struct HcSideStream {
     bool ok = false;
     bool init() {
         if (ok) return true;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return false; }
         for (int k = 0; k < 2; k++)
             if (hipEventCreateWithFlags(&searched[k], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&emitted[k], hipEventDisableTiming) != hipSuccess) return false;
+                hipEventCreateWithFlags(&emitted[k], hipEventDisableTiming) != hipSuccess) { destroy(); return false; }
         ok = true;
         return true;
     }
+    void destroy() {       // also after a partial init(): nothing is left behind for the next attempt to leak
+        for (int k = 0; k < 2; k++) {
+            if (searched[k]) (void)hipEventDestroy(searched[k]);
+            if (emitted[k]) (void)hipEventDestroy(emitted[k]);
+            searched[k] = emitted[k] = nullptr;
+        }
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        ok = false;
+    }
+    // thread exit (the slots are thread_local): a service that calls the HC batch API from short-lived threads gives its
+    // streams and events back.  hipStreamDestroy waits for work still queued on the stream.
+    ~HcSideStream() { destroy(); }
 };
 static HcSideStream *hc_side_stream() {
     static thread_local HcSideStream per_device[16];
@@ -970,14 +983,17 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         HcSideStream *side = (chunk >= 2u && nblocks > chunk / 2u && !no_overlap) ? hc_side_stream() : nullptr;
         const uint32_t sub = side ? chunk / 2u : chunk;
         uint32_t round = 0;
+        // error exit: K3 may still be running on the side stream and the caller parks the workspace as soon as `stream` is
+        // idle -- wait for the side stream first
+        auto fail = [&]() -> int { if (side) (void)hipStreamSynchronize(side->st); return -7; };
         for (uint32_t b0 = 0; b0 < nblocks; b0 += sub, round++) {
             const uint32_t nb = nblocks - b0 < sub ? nblocks - b0 : sub;
             const uint32_t half = side ? (round & 1u) : 0u;
             R *res = d_res + (uint64_t)half * sub * stride;
-            if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return -7;   // K3 of round - 2 read this half
+            if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return fail();   // K3 of round - 2 read this half
             // K2s stores matches only: every other position of the parse must read "no match"
-            if (hipMemsetAsync(res, 0, (size_t)nb * stride * sizeof(R), stream) != hipSuccess) return -7;
-            if (!kLds && hipMemsetAsync(d_bitmap, 0, (size_t)nb * bm_stride * 4u, stream) != hipSuccess) return -7;
+            if (hipMemsetAsync(res, 0, (size_t)nb * stride * sizeof(R), stream) != hipSuccess) return fail();
+            if (!kLds && hipMemsetAsync(d_bitmap, 0, (size_t)nb * bm_stride * 4u, stream) != hipSuccess) return fail();
             hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64 * kLinkWaves), kHcTableSize * 4u + 4096u * sizeof(T) + 16u, stream, d_in,
                                d_in_off, d_in_len, d_link, stride, b0, nb, max_in_len);
             hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), lds, stream, d_in, d_in_off, d_in_len,
@@ -986,16 +1002,16 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
             hipStream_t emit_on = stream;
             if (side) {
                 if (hipEventRecord(side->searched[half], stream) != hipSuccess ||
-                    hipStreamWaitEvent(side->st, side->searched[half], 0) != hipSuccess) return -7;
+                    hipStreamWaitEvent(side->st, side->searched[half], 0) != hipSuccess) return fail();
                 emit_on = side->st;
             }
             hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, emit_on, d_in, d_in_off, d_in_len,
                                d_out, d_out_off, d_out_cap, d_result, static_cast<const R *>(res), stride, b0, nb, max_in_len);
-            if (side && hipEventRecord(side->emitted[half], side->st) != hipSuccess) return -7;
+            if (side && hipEventRecord(side->emitted[half], side->st) != hipSuccess) return fail();
         }
         if (side)     // join: everything enqueued here is ordered before whatever the caller enqueues on `stream` next
             for (uint32_t k = 0; k < 2u && k < round; k++)
-                if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return -7;
+                if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return fail();
         return hipGetLastError() == hipSuccess ? 0 : -7;
     }
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
@@ -1066,7 +1082,7 @@ extern "C" int zlz4_launch_compress_hc(hipStream_t stream, const uint8_t *d_in, 
         uint64_t mid_chunk = ws_bytes / zlz4_hc_mid_workspace_bytes(1);
         if (mid_chunk > nblocks) mid_chunk = nblocks;
         return zlz4_launch_hc_mid(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, ws,
-                                  (uint32_t)mid_chunk);
+                                  (uint32_t)mid_chunk, max_in_len);
     }
     const bool optimal = level >= 10;
     static const int32_t opt_nb[3] = {96, 512, 16384};

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64) void k_hc_mid_serial(const uint8_t *__restrict_
                                                        const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
                                                        const uint64_t *__restrict__ d_out_off,
                                                        const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result,
-                                                       uint32_t *__restrict__ d_tables, uint32_t blk0, uint32_t nblocks) {
+                                                       uint32_t *__restrict__ d_tables, uint32_t blk0, uint32_t nblocks,
+                                                       uint32_t max_in_len) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     const uint32_t blk = blk0 + b;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(64) void k_hc_mid_serial(const uint8_t *__restrict_
     const uint32_t n = d_in_len[blk], oend = d_out_cap[blk];
     int64_t out;
     if (n > kMaxInput) out = kErrInputTooLarge;                                   // :1442
+    else if (n > max_in_len) out = kErrInvalidState;                              // the batch contract (include/zlz4_amd.h)
     else if (n == 0) out = 0;                                                     // :1443
     else if (oend == 0) out = kErrOutputTooSmall;                                 // :1461
     else if (n < kMfLimit + 1u) out = tiny_block_lane(src, dst, oend, n);         // :706-708
@@ -387,7 +389,7 @@ extern "C" size_t zlz4_hc_opt_workspace_bytes(uint32_t chunk_blocks) {
 
 extern "C" int zlz4_launch_hc_mid(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                   uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, int64_t *d_result,
-                                  uint32_t nblocks, void *ws, uint32_t chunk) {
+                                  uint32_t nblocks, void *ws, uint32_t chunk, uint32_t max_in_len) {
     for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
         const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
         if (hipMemsetAsync(ws, 0, zlz4_hc_mid_workspace_bytes(nb), stream) != hipSuccess) return -7;   // :725-726
@@ -395,7 +397,7 @@ extern "C" int zlz4_launch_hc_mid(hipStream_t stream, const uint8_t *d_in, const
         // the lanes that have one); 1 / 2 / 4 / 8: 124.7 / 106.2 / 133.6 / 153.7 ms on 16 384 blocks, 516 / 474 / 498 / 508 on 65 536
         static const uint32_t lanes = [] { const char *e = zlz4_tune_env("ZLZ4_MID_LANES"); const uint32_t v = e ? (uint32_t)atoi(e) : 2u; return v >= 1u && v <= 64u ? v : 2u; }();
         hipLaunchKernelGGL(zlz4::k_hc_mid_serial, dim3((nb + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off, d_in_len, d_out,
-                           d_out_off, d_out_cap, d_result, static_cast<uint32_t *>(ws), b0, nb);
+                           d_out_off, d_out_cap, d_result, static_cast<uint32_t *>(ws), b0, nb, max_in_len);
     }
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }

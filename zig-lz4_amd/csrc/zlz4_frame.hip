@@ -638,6 +638,7 @@ int64_t decompress_frame_impl(hipStream_t st, const uint8_t *d_src, size_t n, ui
         const uint64_t bs = (uint64_t)w[5];
         const uint32_t bc = (flg & 0x10) ? 1u : 0u, cc = ((seg & kSegLast) && (flg & 0x04)) ? 1u : 0u;
         int64_t plan_host[3] = {0, walk_err, 0};
+        int64_t tot[2] = {0, 0};          // host source of an async copy: lives until the call's last synchronisation
         const uint32_t gridb = (nb + 255) / 256 > 1024 ? 1024 : (nb + 255) / 256;
         if (nb) {
             // speculative single pass: block i -> dst + i * block_size, proven afterwards
@@ -687,7 +688,7 @@ int64_t decompress_frame_impl(hipStream_t st, const uint8_t *d_src, size_t n, ui
         }
         if (cc) {                                                                                        // :625-635
             if (src_pos_end + 4 > n) { (void)fc.sync(); return ZLZ4F_ERR_FRAME_SIZE_WRONG; }
-            int64_t tot[2] = {plan_host[0], 0};
+            tot[0] = plan_host[0];
             if (hipMemcpyAsync(dplan, tot, sizeof tot, hipMemcpyHostToDevice, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
             fc.launched();
             hipLaunchKernelGGL(k_content_check, dim3(1), dim3(64), 0, st, d_dst, dplan, d_src + src_pos_end, dplan, 0u,

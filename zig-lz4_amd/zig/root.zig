@@ -184,14 +184,36 @@ pub const device = struct {
 /// Mirror of the `lz4f` namespace (reference src/lz4f.zig); enum/struct shapes as in :64-122.
 pub const lz4f = struct {
     pub const MAGICNUMBER: u32 = 0x184D2204;
-    pub const BlockSizeID = enum(u3) { default = 0, max64KB = 4, max256KB = 5, max1MB = 6, max4MB = 7 };
+    /// reference src/lz4f.zig:57-59
+    pub fn isError(code: usize) bool {
+        return code > @as(usize, @bitCast(@as(isize, -65536)));
+    }
+    pub const BlockSizeID = enum(u3) {
+        default = 0,
+        max64KB = 4,
+        max256KB = 5,
+        max1MB = 6,
+        max4MB = 7,
+
+        /// reference src/lz4f.zig:71-78
+        pub fn toBlockSize(self: BlockSizeID) Error!usize {
+            return switch (self) {
+                .default, .max64KB => 64 * 1024,
+                .max256KB => 256 * 1024,
+                .max1MB => 1024 * 1024,
+                .max4MB => 4 * 1024 * 1024,
+            };
+        }
+    };
     pub const BlockMode = enum(u1) { linked = 0, independent = 1 };
     pub const ContentChecksum = enum(u1) { disabled = 0, enabled = 1 };
     pub const BlockChecksum = enum(u1) { disabled = 0, enabled = 1 };
+    pub const FrameType = enum(u1) { frame = 0, skippableFrame = 1 };
     pub const FrameInfo = struct {
         blockSizeID: BlockSizeID = .default,
         blockMode: BlockMode = .linked,
         contentChecksumFlag: ContentChecksum = .disabled,
+        frameType: FrameType = .frame,   // reference :100-111; compressFrame always writes .frame (:304-351)
         contentSize: u64 = 0,
         dictID: u32 = 0,
         blockChecksumFlag: BlockChecksum = .disabled,
@@ -202,14 +224,18 @@ pub const lz4f = struct {
         autoFlush: bool = false,
         favorDecSpeed: bool = false,
     };
-    /// reference src/lz4f.zig:31-55 (only the members this path can produce) + device additions
-    pub const FrameError = error{
-        Generic, MaxBlockSizeInvalid, HeaderVersionWrong, BlockChecksumInvalid, ReservedFlagSet,
-        AllocationFailed, SrcSizeTooLarge, DstMaxSizeTooSmall, FrameHeaderIncomplete, FrameTypeUnknown,
-        FrameSizeWrong, DecompressionFailed, HeaderChecksumInvalid, ContentChecksumInvalid,
+    /// reference src/lz4f.zig:31-55: every member, under the reference's name (`lz4f.Error`), so that callers that
+    /// switch on it or name `lz4f.Error!usize` compile unchanged; + the two device additions
+    pub const Error = error{
+        Generic, MaxBlockSizeInvalid, BlockModeInvalid, ParameterInvalid, CompressionLevelInvalid, HeaderVersionWrong,
+        BlockChecksumInvalid, ReservedFlagSet, AllocationFailed, SrcSizeTooLarge, DstMaxSizeTooSmall,
+        FrameHeaderIncomplete, FrameTypeUnknown, FrameSizeWrong, SrcPtrWrong, DecompressionFailed,
+        HeaderChecksumInvalid, ContentChecksumInvalid, FrameDecodingAlreadyStarted, CompressionStateUninitialized,
+        ParameterNull, MaxCode, OutOfMemory,
         DeviceError, Unsupported,
     };
-    fn mapFrame(code: i64) FrameError!usize {
+    pub const FrameError = Error;   // the name earlier revisions of this facade used
+    fn mapFrame(code: i64) Error!usize {
         if (code >= 0) return @intCast(code);
         return switch (code) {
             -101 => error.Generic, -102 => error.MaxBlockSizeInvalid, -106 => error.HeaderVersionWrong,
@@ -236,35 +262,35 @@ pub const lz4f = struct {
         return zlz4f_compress_frame_bound(srcSize, null);
     }
     /// the allocator argument of the reference (unused there, src/lz4f.zig:443) is kept for source compatibility
-    pub fn compressFrame(allocator: std.mem.Allocator, src: []const u8, dst: []u8, prefs: ?Preferences) FrameError!usize {
+    pub fn compressFrame(allocator: std.mem.Allocator, src: []const u8, dst: []u8, prefs: ?Preferences) Error!usize {
         _ = allocator;
         if (prefs) |p| { const c = toC(p); return mapFrame(zlz4f_compress_frame(src.ptr, src.len, dst.ptr, dst.len, &c)); }
         return mapFrame(zlz4f_compress_frame(src.ptr, src.len, dst.ptr, dst.len, null));
     }
-    pub fn decompressFrame(allocator: std.mem.Allocator, src: []const u8, dst: []u8) FrameError!usize {
+    pub fn decompressFrame(allocator: std.mem.Allocator, src: []const u8, dst: []u8) Error!usize {
         _ = allocator;
         return mapFrame(zlz4f_decompress_frame(src.ptr, src.len, dst.ptr, dst.len));
     }
-    pub fn headerSize(src: []const u8) FrameError!usize {
+    pub fn headerSize(src: []const u8) Error!usize {
         return mapFrame(zlz4f_header_size(src.ptr, src.len));
     }
 
     /// Device-resident frames (BASELINE configs[4]): `d_src` / `d_dst` are device pointers.
     pub const SEG_FIRST: u32 = 1;
     pub const SEG_LAST: u32 = 2;
-    pub fn compressFrameDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: ?Preferences) FrameError!usize {
+    pub fn compressFrameDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: ?Preferences) Error!usize {
         if (prefs) |p| { const c = toC(p); return mapFrame(zlz4f_compress_frame_device(stream, d_src, src_len, d_dst, dst_cap, &c)); }
         return mapFrame(zlz4f_compress_frame_device(stream, d_src, src_len, d_dst, dst_cap, null));
     }
-    pub fn decompressFrameDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize) FrameError!usize {
+    pub fn decompressFrameDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize) Error!usize {
         return mapFrame(zlz4f_decompress_frame_device(stream, d_src, src_len, d_dst, dst_cap));
     }
     /// one rank's block segment of a frame spread over several GPUs (include/zlz4_amd.h)
-    pub fn compressFrameSegmentDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: Preferences, segment_flags: u32) FrameError!usize {
+    pub fn compressFrameSegmentDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: Preferences, segment_flags: u32) Error!usize {
         const c = toC(prefs);
         return mapFrame(zlz4f_compress_frame_segment_device(stream, d_src, src_len, d_dst, dst_cap, &c, segment_flags));
     }
-    pub fn decompressFrameSegmentDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: Preferences, segment_flags: u32) FrameError!usize {
+    pub fn decompressFrameSegmentDevice(stream: ?*anyopaque, d_src: [*]const u8, src_len: usize, d_dst: [*]u8, dst_cap: usize, prefs: Preferences, segment_flags: u32) Error!usize {
         const c = toC(prefs);
         return mapFrame(zlz4f_decompress_frame_segment_device(stream, d_src, src_len, d_dst, dst_cap, &c, segment_flags));
     }
