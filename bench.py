@@ -169,8 +169,8 @@ def launch_ranks(n):
             rc = 1
     t.join(timeout=10)
     out0 = buf[0] if buf else b""
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
+    for ln in out0.decode(errors="replace").splitlines():      # stdout carries the JSON line only; library chatter -> stderr
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr, flush=True)
     return rc
 
 
