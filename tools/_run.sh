@@ -1,8 +1,10 @@
 set -e
-mkdir -p gpurun_out/r3c
-python -m pytest tests/test_gpu_shipped_paths.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r3c/tests.txt 2>&1 || { tail -40 gpurun_out/r3c/tests.txt; exit 1; }
-tail -3 gpurun_out/r3c/tests.txt
-ZLZ4_BENCH_REHEARSE=1 python3 bench.py --gpus 2 --steps 2 --warmup 1 --blocks 8192 > gpurun_out/r3c/rehearse2.json 2> gpurun_out/r3c/rehearse2.err || { tail -20 gpurun_out/r3c/rehearse2.err; exit 1; }
-cat gpurun_out/r3c/rehearse2.json | cut -c1-400
-ZLZ4_BENCH_REHEARSE=1 python3 bench.py --gpus 2 --workload cfg5 --steps 2 --warmup 1 --blocks 128 > gpurun_out/r3c/rehearse2_cfg5.json 2> gpurun_out/r3c/rehearse2_cfg5.err || { tail -20 gpurun_out/r3c/rehearse2_cfg5.err; exit 1; }
-cat gpurun_out/r3c/rehearse2_cfg5.json | cut -c1-400
+mkdir -p gpurun_out/r3e
+export ZLZ4_AMD_LIB=$PWD/zig-lz4_amd/libzlz4_amd_stamps.so
+echo "== grid 4MiB" > gpurun_out/r3e/stamps2.txt
+ZLZ4_TUNE_GRID=1 python tools/stamp_profile.py text 1024 4194304 >> gpurun_out/r3e/stamps2.txt 2>&1
+echo "== anchored 4MiB" >> gpurun_out/r3e/stamps2.txt
+ZLZ4_TUNE_GRID=0 python tools/stamp_profile.py text 1024 4194304 >> gpurun_out/r3e/stamps2.txt 2>&1
+echo "== grid 64K" >> gpurun_out/r3e/stamps2.txt
+ZLZ4_TUNE_GRID=1 python tools/stamp_profile.py text 65536 >> gpurun_out/r3e/stamps2.txt 2>&1
+grep -v amdgpu.ids gpurun_out/r3e/stamps2.txt

@@ -15,7 +15,7 @@ import zig_lz4_amd as zl
 dist = sys.argv[1] if len(sys.argv) > 1 else "text"
 nblocks = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 dev = torch.device("cuda:0")
-block = 65536
+block = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 slot = (zl.compressBound(block) + 15) // 16 * 16
 inp = bench.make_device_blocks(dist, nblocks, block, dev, seed=1)
 ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
