@@ -669,619 +669,6 @@ __global__ __launch_bounds__(256) void k_compress_fast(
 }
 
 
-// =====================================================================================================================
-// Round 3: the window path on a FIXED GRID, software-pipelined one window deep.
-//
-// In k_compress_fast above a window starts at the anchor the previous window ended with, so nothing of window k+1 can
-// start before the parse of window k is over, and every window pays one dependent trip to memory (table read -> gather
-// of the candidates' bytes -> compare) on top of its instruction time: ~2 000 of ~9 000 wave-cycles per window, and with
-// the LDS table fixing the occupancy at 13..20 wavefronts per CU there is nobody to hide it behind.
-//
-// Here lane i of window w is position 64 w + i whatever the parse does.  The parse state that enters a window is one
-// number, the anchor (the search starts at anchor + 1, src/lz4.zig:317, :435-442):
-//     anchor >= 64 w : lanes below anchor - 64 w are strictly inside the last match (never inserted, Q6), lane
-//                      anchor - 64 w is put but not probed (:438-441), the lanes above it are probed;
-//     anchor <  64 w : a search is under way; the pending literals start in an earlier window; lane i is probe number
-//                      64 w + i - anchor - 1 of that search and is probed with stride 1 while that is <= 65 (:322-338).
-// Because the positions of window w + 1 are known in advance, its forward bytes are loaded two windows early and its
-// table entries are read -- and its candidates gathered -- right after the speculative put of window w, i.e. BEFORE the
-// parse of w has decided which of w's lanes the serial loop really inserted.  What that read can get wrong is exactly the
-// slots window w wrote: it then returns a position inside window w (a value no committed entry can have), those lanes
-// read their slot again after w's commit and gather again (from lines that were just loaded), everybody else's gather
-// has had a whole window of time.  Tags (kTag, see above) keep the early gather to the true candidates' lines.
-// The table is left exactly as the serial loop would have left it after every window, so the generic path (any
-// acceleration, searches longer than 66 probes, the block's tail) takes over and hands back at any window boundary.
-// =====================================================================================================================
-
-// 64 probes of ONE search per step (the generic path of k_compress_fast as a function): probe number ub + lane of the
-// search that starts at F0 (ub == -1: lane 0 is the pending put of F0 - 1, :438-441).  Returns 1 = match (m_*), 0 = bail
-// (:335-338 -> finishCompression).
-template <typename T, int kTag>
-__device__ __forceinline__ int fast_generic_search(
-    const uint8_t *__restrict__ src, __attribute__((address_space(3))) volatile T *table,
-    __attribute__((address_space(3))) volatile uint8_t *tags, uint32_t F0, int32_t ub, bool has_ins, uint32_t accel,
-    uint32_t cbase, uint32_t s_cbase, uint32_t L, uint32_t match_limit, uint32_t src_size, uint32_t lane,
-    uint32_t &m_pos, uint32_t &m_cand, uint32_t &m_local, bool &m_local_done) {
-    constexpr uint32_t kPosMask = kTag == 2 ? 0x00FFFFFFu : 0xFFFFFFFFu;
-    const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
-    for (;;) {
-        const int32_t u = ub + (int32_t)lane;
-        uint32_t pos, step_next;
-        if (u <= 0) {
-            pos = (u < 0) ? F0 - 1u : F0;
-            step_next = accel;
-        } else if (u == 1) {
-            pos = F0 + accel;
-            step_next = accel >> 6;
-        } else {
-            const uint32_t x = cbase + (uint32_t)u - 1u;
-            pos = F0 + accel + skip_sum(x) - s_cbase;
-            step_next = x >> 6;
-        }
-        const bool is_probe = u >= 0;
-        const bool bail = is_probe && ((uint64_t)pos + step_next > L);
-        const uint64_t bail_mask = ballot(bail);
-        const uint32_t nb = bail_mask ? first_lane(bail_mask) : 64u;
-        const bool active = (lane < nb) && (is_probe || has_ins);
-        const bool have16 = active && (pos + 16u <= src_size);
-        u32x4 fwd = {0, 0, 0, 0};
-        if (have16) fwd = ld128(src + pos);
-        else if (active) fwd.x = ld32(src + pos);
-        const uint32_t prod = fwd.x * kHashMul;
-        const uint32_t h = prod >> 20;                                  // :341
-        const uint32_t tg = (prod >> 12) & 0xFFu;
-        const uint32_t mine = kTag == 2 ? (pos | (tg << 24)) : (uint32_t)(T)pos;
-        uint32_t old_e = 0, rb = 0, told = tg;
-        if (active) {
-            old_e = table[h];                                           // :342
-            if (kTag == 1) told = tags[h];
-            table[h] = (T)mine;                                         // :350 (speculative)
-        }
-        if (kTag == 2) told = old_e >> 24;
-        const uint32_t old = old_e & kPosMask;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (active) rb = table[h];
-        uint64_t losers = ballot(active && rb != mine);
-        uint64_t grp = lane_bit;
-        int32_t pred = -1;
-        while (losers) {
-            const uint32_t l = first_lane(losers);
-            const uint32_t hh = rdlane(h, l);
-            const uint64_t same = ballot(active && h == hh);
-            if (active && h == hh) {
-                grp = same;
-                const uint64_t below = same & lanes_below;
-                pred = below ? 63 - (int32_t)__clzll((long long)below) : -1;
-            }
-            losers &= ~same;
-        }
-        const uint32_t pred_pos = shfl(pos, (uint32_t)(pred < 0 ? 0 : pred));
-        const uint32_t cand = pred >= 0 ? pred_pos : old;
-        bool valid = is_probe && active && cand > 0 && cand < pos && (cand + kMaxDist >= pos) &&
-                     (kTag == 0 || pred >= 0 || told == tg);
-        u32x4 cnd = {0, 0, 0, 0};
-        if (valid) {
-            if (have16) cnd = ld128(src + cand); else cnd.x = ld32(src + cand);
-            valid = cnd.x == fwd.x;
-        }
-        const uint64_t valid_mask = ballot(valid);
-        if (valid_mask) {
-            const uint32_t wl = first_lane(valid_mask);
-            if (active && lane > wl) table[h] = (T)old_e;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const uint64_t upto = (2ull << wl) - 1ull;
-            if (active && lane <= wl && ((grp & upto & ~lanes_below & ~lane_bit) == 0)) {
-                table[h] = (T)mine;
-                if (kTag == 1) tags[h] = (uint8_t)tg;
-            }
-            uint32_t loc = 0;
-            bool loc_done = false;
-            if (lane == wl) {
-                const uint32_t lim = match_limit - (pos + kMinMatch);
-                if (have16) {
-                    u32x4 a = fwd, b = cnd;
-                    a.x = 0; b.x = 0;
-                    loc = first_diff16(a, b) - 4u;
-                    if (loc >= lim) { loc = lim; loc_done = true; }
-                    else if (loc < 12u) loc_done = true;
-                }
-            }
-            m_pos = rdlane(pos, wl);
-            m_cand = rdlane(cand, wl);
-            m_local = rdlane(loc, wl);
-            m_local_done = rdlane((uint32_t)loc_done, wl) != 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            return 1;
-        }
-        if (bail_mask) return 0;
-        if (active && ((grp & ~lanes_below & ~lane_bit) == 0)) {
-            if (grp != lane_bit) table[h] = (T)mine;
-            if (kTag == 1) tags[h] = (uint8_t)tg;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        ub += 64;
-    }
-}
-
-template <typename T, int kTag>   // kTag 1 (u16 table + u8 tags) or 2 (u32 entries, tag in bits 24..31)
-__global__ __launch_bounds__(256) void k_compress_fast_grid(
-    const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
-    const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
-    const uint64_t *__restrict__ d_out_off, const uint32_t *__restrict__ d_out_cap,
-    int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t acceleration, uint32_t max_in_len) {
-    static_assert(kTag == 1 || kTag == 2, "the early gather wants tags");
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_in_wg = threadIdx.x >> 6;
-    const uint32_t blk = rfl(blockIdx.x * (blockDim.x >> 6) + wave_in_wg);
-    if (blk >= nblocks) return;
-    typedef __attribute__((address_space(3))) volatile T lds_entry;
-    typedef __attribute__((address_space(3))) volatile uint8_t lds_tag;
-    lds_entry *table = (lds_entry *)lds_raw + wave_in_wg * 4096u;
-    lds_tag *tags = (lds_tag *)lds_raw + (blockDim.x >> 6) * 4096u * (uint32_t)sizeof(T) + wave_in_wg * 4096u;
-    constexpr uint32_t kPosMask = kTag == 2 ? 0x00FFFFFFu : 0xFFFFFFFFu;
-
-    const uint8_t *src = d_in + d_in_off[blk];
-    uint8_t *dst = d_out + d_out_off[blk];
-    const uint32_t src_size = rfl(d_in_len[blk]);
-    const uint32_t dst_len = rfl(d_out_cap[blk]);
-
-    int64_t res;
-    if (src_size > kMaxInput) {                                         // :296
-        res = kErrInputTooLarge;
-    } else if (src_size > max_in_len) {
-        res = kErrInvalidState;
-    } else if (src_size == 0) {                                         // :299
-        res = 0;
-    } else if (src_size < kMfLimit + 1u) {                              // :302-304
-        res = emit_last_literals(dst, dst_len, 0, src, src_size, lane);
-    } else {
-        {   // HashTable.init(): zero fill (:266-268)
-            u32x4 z = {0, 0, 0, 0};
-            u32x4 *t4 = reinterpret_cast<u32x4 *>(lds_raw) + wave_in_wg * (4096u * sizeof(T) / 16u);
-            const uint32_t n16 = 4096u * sizeof(T) / 16u;
-            for (uint32_t k = lane; k < n16; k += 64u) t4[k] = z;
-        }
-        const uint32_t accel = acceleration < 1u ? 1u : (acceleration > 65537u ? 65537u : acceleration);   // :321
-        const uint32_t cbase = accel > 64u ? accel : 64u;
-        const uint32_t s_cbase = skip_sum(cbase);
-        const uint32_t L = src_size - kMfLimit;                         // mflimitPlusOne :313
-        const uint32_t match_limit = src_size - kLastLiterals;          // :314
-        const uint64_t lane_bit = 1ull << lane;
-        const uint64_t lanes_below = lane_bit - 1ull;
-
-        uint32_t anchor = 0, op = 0;
-        uint32_t F0 = 1;                                                // :317
-        bool has_ins = false;    // pending put(anchor) of :438-441
-        bool failed = false;
-        uint32_t guard = 0;
-        STAMP_DECL
-        STAMP(0);
-        // a window may run on the grid if it and the loads issued for the two windows after it stay inside the block and
-        // clear of the block's tail rules (:313-314): 64 w + 320 < L
-        auto grid_ok = [&](uint32_t w) -> bool { return (uint64_t)(w << 6) + 320u < L; };
-
-        while (F0 < L) {                                                // :320
-            if (++guard > src_size) { failed = true; break; }           // unreachable; never spin on the GPU
-            int32_t ub = -1;
-
-            if (accel == 1u && (has_ins || anchor == 0u) && grid_ok(anchor >> 6)) {
-                // ================= grid windows =================
-                uint32_t w = anchor >> 6;
-                bool pipe = false;                  // the n_* registers hold window w's early reads
-                bool to_generic = false;
-                int32_t gen_ub = 0;
-                uint32_t last_W = w << 6;          // the last window that was processed
-                // pipeline registers: n_* = the window about to be processed (forward bytes, early table read, early
-                // gather), nn_fwd = forward bytes of the window after it.  They are rotated at ONE point per window,
-                // after the parse and before the emission: the compiler waits for a load where its registers are first
-                // read, and a rotation at the loop's back edge would wait behind the emission's stores every window.
-                u32x4 n_fwd = {0, 0, 0, 0}, nn_fwd = {0, 0, 0, 0}, n_cold = {0, 0, 0, 0}, n_c2 = {0, 0, 0, 0};
-                u32x4 p_fwd = {0, 0, 0, 0};        // forward bytes of the window before (candidates 1..64 positions back)
-                uint32_t n_olde = 0, n_told = 0;
-                bool n_coll = false, n_ok = false;
-#define ZLZ4_PIN4(v) asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
-                for (;;) {
-                    if (++guard > src_size) { failed = true; break; }
-                    const uint32_t W = w << 6;
-                    last_W = W;
-                    const int32_t a_lane = (int32_t)(anchor - W);       // < 0: the search started in an earlier window
-                    // last lane the search under way still probes with stride 1 (probe number of lane i = i - a_lane - 1 <= 65)
-                    const int32_t flim = a_lane + 66;
-                    if (flim < 0) { to_generic = true; gen_ub = -a_lane - 1; break; }   // nothing of this window is stride 1
-                    const uint32_t pos = W + lane;
-                    if (!pipe) {
-                        // cold start: every lane reads its slot below and gathers from memory.  (The loads are awaited
-                        // inside the branch -- pinned -- so that the steady state's path through the join has no load
-                        // pending here and does not wait for the last emission's stores.)
-                        n_fwd = ld128(src + pos);
-                        nn_fwd = ld128(src + pos + 64u);
-                        ZLZ4_PIN4(n_fwd); ZLZ4_PIN4(nn_fwd);
-                        n_coll = true;
-                        n_ok = false; n_olde = 0; n_told = 0; n_cold = u32x4{0, 0, 0, 0}; n_c2 = u32x4{0, 0, 0, 0};
-                    }
-                    const u32x4 fwd = n_fwd;
-                    // bytes 16..31 ahead of every lane (second compare level): lines the forward loads have already
-                    // brought in; asked for now, needed after the table work below
-                    const u32x4 f2 = ld128(src + pos + 16u);
-                    u32x4 cold = n_cold, c2 = n_c2;
-                    uint32_t old_e = n_olde, told = n_told;
-                    const bool coll = n_coll;
-                    bool ok = n_ok;
-                    const uint32_t litb = fwd.x;                        // the lane's literal byte (:390)
-                    const uint32_t prod = fwd.x * kHashMul;
-                    const uint32_t h = prod >> 20;                      // :341
-                    const uint32_t tg = (prod >> 12) & 0xFFu;
-                    const uint32_t mine = kTag == 2 ? (pos | (tg << 24)) : (uint32_t)(T)pos;
-                    STAMP(1);
-                    STAMP_COUNT(16);
-                    // ---- lanes whose early read may have seen the previous window's speculative puts (or a cold start):
-                    //      the slot again, now that the table is exact, and the candidate's bytes again ----
-                    if (ballot(coll)) {
-                        if (coll) {
-                            old_e = table[h];                           // :342
-                            if (kTag == 1) told = tags[h];
-                        }
-                        if (kTag == 2) told = old_e >> 24;
-                        const uint32_t o2 = old_e & kPosMask;
-                        const bool ok2 = o2 > 0 && (o2 + kMaxDist >= pos) && told == tg;
-                        // a candidate inside the window before (the usual case: that is what the early read collided with)
-                        // is served from that window's forward registers: lane o2 - (W - 64) holds the 16 bytes at o2,
-                        // and the next 16 are the bytes of lane + 16 (of that window, or of this one)
-                        const bool in_prev = pipe && o2 + 64u >= W;     // (cold start: p_fwd holds nothing of use)
-                        const uint32_t sl = (o2 + 64u - W) & 63u, sl2 = (sl + 16u) & 63u;
-                        const u32x4 pc = {shfl(p_fwd.x, sl), shfl(p_fwd.y, sl), shfl(p_fwd.z, sl), shfl(p_fwd.w, sl)};
-                        const u32x4 pa = {shfl(p_fwd.x, sl2), shfl(p_fwd.y, sl2), shfl(p_fwd.z, sl2), shfl(p_fwd.w, sl2)};
-                        const u32x4 pb = {shfl(fwd.x, sl2), shfl(fwd.y, sl2), shfl(fwd.z, sl2), shfl(fwd.w, sl2)};
-                        const bool from_mem = coll && ok2 && !in_prev;
-                        if (coll) {
-                            ok = ok2;
-                            cold = pc;
-                            c2 = sl < 48u ? pa : pb;
-                        }
-                        if (ballot(from_mem)) {
-                            if (from_mem) { cold = ld128(src + o2); c2 = ld128(src + o2 + 16u); }
-                        }
-                    }
-                    const uint32_t old = old_e & kPosMask;
-                    // lanes of this window that exist for the serial loop: the anchor's lane (put only; position 0 never, Q1)
-                    // and everything above it
-                    const bool wr = a_lane < 0 || (int32_t)lane > a_lane || ((int32_t)lane == a_lane && anchor != 0u);
-                    const bool old_ok = wr && ok;
-                    STAMP(3);
-                    uint32_t rb = 0;
-                    if (wr) table[h] = (T)mine;                         // :350 (speculative)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    if (wr) rb = table[h];
-                    uint64_t losers = ballot(wr && rb != mine);
-                    uint64_t grp = lane_bit;
-                    while (losers) {                                    // one round per duplicate-hash group
-                        const uint32_t l = first_lane(losers);
-                        const uint32_t hh = rdlane(h, l);
-                        const uint64_t same = ballot(wr && h == hh);
-                        if (wr && h == hh) grp = same;
-                        losers &= ~same;
-                    }
-                    STAMP(2);
-
-                    // first compare level (the candidates' bytes were asked for a window ago)
-                    const bool vo = old_ok && cold.x == fwd.x;
-                    uint32_t mlo;
-                    {
-                        const uint32_t x1 = fwd.y ^ cold.y, x2 = fwd.z ^ cold.z, x3 = fwd.w ^ cold.w;
-                        const uint32_t xs = x1 ? x1 : (x2 ? x2 : x3);
-                        const uint32_t xbase = x1 ? 0u : (x2 ? 4u : 8u);
-                        mlo = xs ? xbase + ((uint32_t)__builtin_ctz(xs) >> 3) : 12u;
-                    }
-                    // second level from registers (f2 / c2); a third on demand for the few matches of 32 bytes and more, asked
-                    // for BEFORE the next window's gather (loads return in order: waiting for these must not mean waiting
-                    // for that)
-                    if (vo && mlo == 12u) mlo += first_diff16_sel(f2, c2);
-                    const bool lvl3 = vo && mlo == 28u;
-                    u32x4 f3 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
-                    if (lvl3) { f3 = ld128(src + pos + 32u); c3 = ld128(src + old + 32u); }
-                    // ---- early reads for window w + 1: its slots as they are now (this window's speculative puts in
-                    //      place), its candidates' bytes, and the forward bytes of window w + 2 ----
-                    // (unconditional: a window on the grid has room for these loads, see grid_ok, and with a fixed number
-                    //  of loads behind the second level's the compiler can wait for those with vmcnt(2) instead of vmcnt(0))
-                    const bool next_ok = grid_ok(w + 1u);
-                    const uint32_t prod_n = nn_fwd.x * kHashMul;
-                    const uint32_t h_n = prod_n >> 20, tg_n = (prod_n >> 12) & 0xFFu;
-                    const uint32_t e_olde = table[h_n];
-                    const uint32_t e_told = kTag == 1 ? (uint32_t)tags[h_n] : (e_olde >> 24);
-                    const uint32_t o_n = e_olde & kPosMask;
-                    const bool e_coll = o_n >= W;                       // a position of THIS window: not a committed entry
-                    const bool e_ok = o_n > 0 && !e_coll && (o_n + kMaxDist >= pos + 64u) && e_told == tg_n;
-                    const uint32_t e_at = e_ok ? o_n : pos;             // (lanes without a candidate re-read their own line)
-                    const u32x4 e_cold = ld128(src + e_at);
-                    const u32x4 e_c2 = ld128(src + e_at + 16u);
-                    const u32x4 e_fwd = ld128(src + pos + 128u);
-                    if (lvl3) mlo += first_diff16_sel(f3, c3);
-                    const bool single = grp == lane_bit;
-                    const bool oldfast = vo && mlo < 44u;
-                    const uint64_t wrmask = ballot(wr);
-                    const uint64_t cfast = ballot(oldfast);
-                    const uint64_t slow = ballot(wr && ((!single && !oldfast) || (vo && mlo >= 44u)));
-                    const uint64_t nsing = ballot(wr && !single);
-                    uint32_t J, S;
-                    {
-                        const uint64_t mj = cfast >> lane, ms = slow >> lane;
-                        J = mj ? lane + (uint32_t)__builtin_ctzll(mj) : 64u;
-                        S = ms ? lane + (uint32_t)__builtin_ctzll(ms) : 64u;
-                    }
-                    uint32_t v_end = lane + kMinMatch + mlo;
-                    uint32_t mlo_e = mlo, off_e = pos - old;
-                    uint32_t XP, Q;
-                    {
-                        const uint32_t xm = J < S ? J : S;
-                        XP = xm | ((uint32_t)((nsing >> (xm & 63u)) & 1ull) << 7);
-                        Q = (vo ? 1u : 0u) | (mlo << 1);
-                    }
-                    uint32_t PK;
-                    {
-                        const uint32_t jc = J & 63u;
-                        const uint32_t ve_j = shfl(v_end, jc);
-                        const bool fastok = J < 64u && S > J && !((nsing >> jc) & 1ull);
-                        PK = fastok ? (J | (ve_j << 6)) : 0xFFFFFFFFu;
-                    }
-                    STAMP(6);
-
-                    uint32_t f = a_lane < 0 ? 0u : (uint32_t)a_lane + 1u;   // next lane to probe
-                    int32_t a = a_lane;      // lane of the current anchor (negative: in an earlier window)
-                    uint32_t nseq = 0;
-                    uint64_t covered_x = 0;
-                    uint64_t mm_win = 0;
-                    const bool tight = dst_len - op < 1024u;
-                    int32_t a0 = a;
-                    uint32_t op0 = op;
-                    uint64_t mm_run = 0;
-                    auto covered_now = [&]() -> uint64_t {
-                        const uint64_t mb = (mm_win | mm_run) & lanes_below;
-                        const uint32_t pj = mb ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;
-                        const uint32_t pe = shfl(v_end, pj);
-                        return covered_x | ballot(mb != 0 && lane < pe);
-                    };
-                    // flush of the pending run.  Its first sequence may own literals of earlier windows (a0 < 0): they are
-                    // copied from memory, everything the lanes write moves up by their number.
-                    auto flush_run = [&]() {
-                        STAMP(9); STAMP_COUNT(21);
-                        const uint32_t pre = a0 < 0 ? (uint32_t)(-a0) : 0u;
-                        const uint64_t mb = mm_run & lanes_below;
-                        const bool has_prev = mb != 0;
-                        const uint32_t pj = has_prev ? 63u - (uint32_t)__builtin_clzll(mb) : 0u;
-                        const uint32_t pend_all = shfl(v_end, pj);
-                        const int32_t pend = has_prev ? (int32_t)pend_all : a0;      // first lane of my literal run
-                        const bool cov = has_prev && lane < pend_all;
-                        const bool is_m = (mm_run & lane_bit) != 0;
-                        const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(mm_run);
-                        const bool is_lit = (int32_t)lane >= a0 && lane < jlast && !cov && !is_m;
-                        const uint64_t litmask = ballot(is_lit);
-                        const uint64_t extm = ballot(is_m && mlo_e >= 15u);
-                        const uint64_t at_or_above = mm_run & ~lanes_below;
-                        const uint32_t my_m = at_or_above ? (uint32_t)__builtin_ctzll(at_or_above) : lane;
-                        const uint32_t own_l = ((int32_t)my_m - pend >= 15) ? 1u : 0u;
-                        const uint64_t lextm = ballot(is_m && own_l != 0u);
-                        const uint32_t k = (uint32_t)__popcll(mb);
-                        const uint32_t lb = (uint32_t)__popcll(litmask & lanes_below);
-                        const uint32_t o1 = op0 + pre + 3u * k + lb + 1u + (uint32_t)__popcll(extm & lanes_below) +
-                                            (uint32_t)__popcll(lextm & lanes_below) + own_l;
-                        if (is_lit) dst[o1] = (uint8_t)litb;                // literals (:390)
-                        if (is_m) {
-                            const uint32_t lit_k = (uint32_t)((int32_t)lane - pend);     // :360
-                            uint8_t *tk = dst + (o1 - 1u - lit_k - own_l);
-                            tk[0] = (uint8_t)(((lit_k < 15u ? lit_k : 15u) << 4) | (mlo_e < 15u ? mlo_e : 15u));
-                            if (own_l) tk[1] = (uint8_t)(lit_k - 15u);      // < 255: lit_k <= 66 + 63
-                            const uint16_t off16 = (uint16_t)off_e;         // :395
-                            __builtin_memcpy(dst + o1, &off16, 2);
-                            if (mlo_e >= 15u) dst[o1 + 2u] = (uint8_t)(mlo_e - 15u);
-                        }
-                        if (pre) {
-                            // the first sequence's literals of earlier windows: right behind its token (+ extension byte)
-                            const uint32_t j1 = (uint32_t)__builtin_ctzll(mm_run);
-                            const uint32_t ol1 = ((int32_t)j1 - a0 >= 15) ? 1u : 0u;
-                            copy_bytes(dst + op0 + 1u + ol1, src + (W - pre), pre, lane);
-                        }
-                        const uint32_t nm = (uint32_t)__popcll(mm_run);
-                        op = op0 + pre + 3u * nm + (uint32_t)__popcll(litmask) + (uint32_t)__popcll(extm) + (uint32_t)__popcll(lextm);
-                        mm_win |= mm_run;
-                        mm_run = 0;
-                        STAMP(10);
-                    };
-                    bool stop_generic = false;      // the search under way leaves the stride-1 range inside this window
-                    for (;;) {
-                        // the first search of the window may run out of its stride-1 probes before lane 63
-                        if (nseq == 0u && flim < 63) {
-                            const uint32_t x0 = f < 64u ? (rdlane(XP, f) & 127u) : 64u;
-                            if ((int32_t)x0 > flim) { stop_generic = true; break; }
-                        }
-                        if (mm_run == 0) { a0 = a; op0 = op; }
-                        if (!tight) {
-                            uint32_t t_pk, t_j, a_u = (uint32_t)a;
-#define ZLZ4_FAST_RUN_TRIP                                   \
-                            "s_cmp_gt_u32 %[f], 63\n\t"      \
-                            "s_cbranch_scc1 3f\n\t"          \
-                            "v_readlane_b32 %[pk], %[PK], %[f]\n\t" \
-                            "s_cmp_eq_u32 %[pk], -1\n\t"     \
-                            "s_cbranch_scc1 3f\n\t"          \
-                            "s_lshr_b32 %[a], %[pk], 6\n\t"  \
-                            "s_add_u32 %[f], %[a], 1\n\t"    \
-                            "s_and_b32 %[j], %[pk], 63\n\t"  \
-                            "s_bitset1_b64 %[mm], %[j]\n\t"  \
-                            "s_add_u32 %[nseq], %[nseq], 1\n\t"
-                            asm volatile(
-                                "s_nop 3\n"
-                                "1:\n\t"
-                                ZLZ4_FAST_RUN_TRIP
-                                ZLZ4_FAST_RUN_TRIP
-                                "s_branch 1b\n"
-                                "3:\n"
-                                : [f] "+s"(f), [a] "+s"(a_u), [nseq] "+s"(nseq), [mm] "+s"(mm_run), [pk] "=&s"(t_pk), [j] "=&s"(t_j)
-                                : [PK] "v"(PK)
-                                : "scc");
-#undef ZLZ4_FAST_RUN_TRIP
-                            a = (int32_t)a_u;
-                        }
-                        STAMP(8);
-                        if (f >= 64u) break;     // window done
-                        const uint32_t xp = rdlane(XP, f);
-                        const uint32_t x = xp & 127u;
-                        if (x >= 64u) break;     // nothing left that can match: the search goes on in the next window
-                        if (nseq == 0u && (int32_t)x > flim) { stop_generic = true; break; }
-                        uint64_t pm = 0;
-                        if (xp >> 7) {
-                            const uint64_t grp_x = (uint64_t)rdlane((uint32_t)grp, x) | ((uint64_t)rdlane((uint32_t)(grp >> 32), x) << 32);
-                            pm = grp_x & wrmask & ~covered_now() & ((1ull << x) - 1ull);
-                        }
-                        const uint32_t j = x;
-                        const uint32_t m_pos = W + j;
-                        uint32_t m_cand, mlen;
-                        if (pm) {
-                            const uint32_t pr = 63u - (uint32_t)__builtin_clzll(pm);
-                            if (rdlane(fwd.x, pr) != rdlane(fwd.x, x)) { STAMP_COUNT(19); STAMP(9); f = x + 1u; continue; }   // :348
-                            STAMP_COUNT(18);
-                            m_cand = W + pr;
-                            const uint64_t xa = ((uint64_t)(rdlane(fwd.z, j) ^ rdlane(fwd.z, pr)) << 32) | (rdlane(fwd.y, j) ^ rdlane(fwd.y, pr));
-                            const uint32_t xb = rdlane(fwd.w, j) ^ rdlane(fwd.w, pr);
-                            if (xa) mlen = (uint32_t)__builtin_ctzll(xa) >> 3;
-                            else if (xb) mlen = 8u + ((uint32_t)__builtin_ctz(xb) >> 3);
-                            else mlen = extend_match(src, m_pos, m_cand, 12u, match_limit, src_size, lane);
-                        } else {
-                            const uint32_t q = rdlane(Q, x);
-                            if (!(q & 1u)) { STAMP_COUNT(19); STAMP(9); f = x + 1u; continue; }
-                            STAMP_COUNT(18);
-                            mlen = q >> 1;
-                            if (mlen < 44u && !tight) {
-                                mm_run |= 1ull << j;
-                                nseq++;
-                                a = (int32_t)(j + kMinMatch + mlen);
-                                STAMP(9);
-                                if (a >= 64) break;
-                                f = (uint32_t)a + 1u;
-                                continue;
-                            }
-                            m_cand = rdlane(old, x);
-                            if (mlen >= 44u) mlen = extend_match(src, m_pos, m_cand, 44u, match_limit, src_size, lane);
-                        }
-                        const uint32_t lit = (uint32_t)((int32_t)j - a);
-                        const uint32_t offset = m_pos - m_cand;
-                        const uint32_t e = j + kMinMatch + mlen;                // lane of the new anchor (may be >= 64)
-                        if (!tight && mlen < 270u) {
-                            v_end = wrlane(e, j, v_end);
-                            mlo_e = wrlane(mlen, j, mlo_e);
-                            off_e = wrlane(offset, j, off_e);
-                            mm_run |= 1ull << j;
-                            nseq++;
-                            a = (int32_t)e;
-                            STAMP(9);
-                            if (e >= 64u) break;
-                            f = e + 1u;
-                            continue;
-                        }
-                        if (mm_run) flush_run();
-                        // immediate emission (:360-432); the literals come from memory (they may start in an earlier window)
-                        const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
-                        const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
-                        if (seq_end > dst_len) { failed = true; break; }
-                        if (lane == 0)
-                            dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (mlen >= 15u ? 15u : mlen));
-                        if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
-                        uint8_t *o = dst + op + 1u + nle;
-                        copy_bytes(o, src + (m_pos - lit), lit, lane);
-                        o += lit;
-                        if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));
-                        if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
-                        op = (uint32_t)seq_end;
-                        {
-                            const uint64_t upto_e = e >= 64u ? ~0ull : (1ull << e) - 1ull;
-                            covered_x |= upto_e & ~((2ull << j) - 1ull);        // lanes j+1 .. e-1
-                        }
-                        nseq++;
-                        a = (int32_t)e;
-                        if (e >= 64u) break;
-                        f = e + 1u;
-                    }
-                    // ---- rotate the pipeline registers (see their declaration) ----
-                    p_fwd = fwd;
-                    n_fwd = nn_fwd; nn_fwd = e_fwd; n_cold = e_cold; n_c2 = e_c2; n_olde = e_olde; n_told = e_told; n_coll = e_coll; n_ok = e_ok;
-                    // (pinned: plain copies would be sunk to the back edge as phi copies)
-                    ZLZ4_PIN4(n_fwd); ZLZ4_PIN4(nn_fwd); ZLZ4_PIN4(n_cold); ZLZ4_PIN4(n_c2);
-                    if (mm_run && !failed) flush_run();
-                    anchor = W + (uint32_t)a;        // (a < 0: unchanged)
-                    STAMP(4);
-                    // lanes the serial loop put(): everything it probed (the whole window, or up to the end of the search's
-                    // stride-1 range) that is not strictly inside a match
-                    const uint32_t f_end = stop_generic ? (uint32_t)(flim + 1) : 64u;
-                    const uint64_t ins = wrmask & ~covered_now() & (f_end >= 64u ? ~0ull : (1ull << f_end) - 1ull);
-                    if (failed) break;
-                    if (wr && !(ins & lane_bit)) table[h] = (T)old_e;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    if ((ins & lane_bit) && (grp & ins & ~lanes_below & ~lane_bit) == 0) {
-                        table[h] = (T)mine;
-                        if (kTag == 1) tags[h] = (uint8_t)tg;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    STAMP(5);
-                    if (stop_generic) { to_generic = true; gen_ub = flim - a_lane; break; }
-                    if (anchor >= L) break;                           // :435-437 the loop condition fails
-                    const uint32_t wn = anchor >= W + 64u ? (anchor >> 6) : w + 1u;
-                    if (!grid_ok(wn)) break;
-                    pipe = next_ok && wn == w + 1u;
-                    w = wn;
-                }
-#undef ZLZ4_PIN4
-                if (failed) break;
-                if (to_generic) {
-                    // the search that started at anchor + 1 goes on at probe number gen_ub; the anchor's put is done
-                    F0 = anchor + 1u;
-                    has_ins = false;
-                    ub = gen_ub;
-                } else if (anchor >= L) {
-                    F0 = L; has_ins = false;
-                    continue;
-                } else if (anchor >= last_W + 64u) {
-                    // the grid ends here (block tail) with a match that ran past the last window: fresh search, the
-                    // anchor's put pending
-                    F0 = anchor + 1u; has_ins = true; ub = -1;
-                } else {
-                    // ... or with a search under way that has probed every position below the next window
-                    F0 = anchor + 1u; has_ins = false; ub = (int32_t)(last_W + 64u - anchor) - 1;
-                }
-            }
-            uint32_t m_pos = 0, m_cand = 0, m_local = 0;
-            bool m_local_done = false;
-            const int found = fast_generic_search<T, kTag>(src, table, tags, F0, ub, has_ins, accel, cbase, s_cbase, L,
-                                                            match_limit, src_size, lane, m_pos, m_cand, m_local, m_local_done);
-            if (!found) break;
-            STAMP_COUNT(20);
-            const uint32_t mlen = m_local_done ? m_local
-                                               : extend_match(src, m_pos, m_cand, m_local, match_limit, src_size, lane);
-            const uint32_t lit = m_pos - anchor;                        // :360
-            const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(mlen);
-            const uint64_t seq_end = (uint64_t)op + 1u + nle + lit + 2u + nme;
-            if (seq_end > dst_len) { failed = true; break; }
-            if (lane == 0)
-                dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (mlen >= 15u ? 15u : mlen));
-            if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
-            uint8_t *o = dst + op + 1u + nle;
-            copy_bytes(o, src + anchor, lit, lane);                     // :390
-            o += lit;
-            const uint32_t offset = m_pos - m_cand;                     // :395
-            if (lane < 2u) o[lane] = (uint8_t)(offset >> (8u * lane));  // :397
-            if (mlen >= 15u) write_ext_len(o + 2u, mlen, lane);
-            op = (uint32_t)seq_end;
-            const uint32_t end = m_pos + kMinMatch + mlen;
-            anchor = end;
-            if (end < L) { has_ins = true; F0 = end + 1u; }
-            else { has_ins = false; F0 = L; }
-        }
-        res = failed ? kErrOutputTooSmall
-                     : emit_last_literals(dst, dst_len, op, src + anchor, src_size - anchor, lane);   // :337, :446
-        STAMP(7);
-        STAMP_FLUSH;
-    }
-    if (lane == 0) d_result[blk] = res;
-}
-
 }  // namespace zlz4
 
 extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in, const uint64_t *d_in_off,
@@ -1297,8 +684,6 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
     // LDS, 20 -> 13 wavefronts per CU, and lose (configs[1] 42.8 -> 54.0 ms; profiles/r03_fast_compress_tags.md), so
     // the u16 build carries them only when asked to (tuning build: ZLZ4_TUNE_TAG=1)
     static const int tune_tag = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_TAG"); return e ? atoi(e) : -1; }();
-    // grid = the pipelined fixed-grid window path (k_compress_fast_grid); 0 = the anchored windows of rounds 1-2
-    static const int tune_grid = [] { const char *e = zlz4_tune_env("ZLZ4_TUNE_GRID"); return e ? atoi(e) : 0; }();
 #define ZLZ4_LAUNCH_FAST(KERN, T, TAG, WPW, LDS)                                                                      \
     hipLaunchKernelGGL((zlz4::KERN<T, TAG>), dim3((nblocks + (WPW) - 1) / (WPW)), dim3(64 * (WPW)), (LDS),              \
                        stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, acceleration,  \
@@ -1308,18 +693,13 @@ extern "C" int zlz4_launch_compress_fast(hipStream_t stream, const uint8_t *d_in
         // one-wave workgroups measured 5 % faster than four-wave ones on MI355X (44.1 / 45.0 / 46.6 ms for 1 / 2 / 4 on
         // configs[1]): a finished block frees its slot at once instead of waiting for the slowest of four
         const uint32_t wpw = (tune_wpw == 2 || tune_wpw == 4) ? tune_wpw : 1;
-        if (tune_grid) ZLZ4_LAUNCH_FAST(k_compress_fast_grid, uint16_t, 1, wpw, wpw * (4096 * sizeof(uint16_t) + 4096) + lds_pad);
-        else if (tune_tag > 0) ZLZ4_LAUNCH_FAST(k_compress_fast, uint16_t, 1, wpw, wpw * (4096 * sizeof(uint16_t) + 4096) + lds_pad);
+        if (tune_tag > 0) ZLZ4_LAUNCH_FAST(k_compress_fast, uint16_t, 1, wpw, wpw * (4096 * sizeof(uint16_t) + 4096) + lds_pad);
         else ZLZ4_LAUNCH_FAST(k_compress_fast, uint16_t, 0, wpw, wpw * 4096 * sizeof(uint16_t) + lds_pad);
     } else {
         const uint32_t wpw = (tune_wpw == 2) ? 2 : 1;   // 16 KiB of LDS per wavefront -> 10 wavefronts per CU
         // positions below 2^24 leave the top byte of a u32 entry to the tag
-        if (tune_tag != 0 && max_in_len <= (1u << 24)) {
-            if (tune_grid) ZLZ4_LAUNCH_FAST(k_compress_fast_grid, uint32_t, 2, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
-            else ZLZ4_LAUNCH_FAST(k_compress_fast, uint32_t, 2, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
-        } else {
-            ZLZ4_LAUNCH_FAST(k_compress_fast, uint32_t, 0, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
-        }
+        if (tune_tag != 0 && max_in_len <= (1u << 24)) ZLZ4_LAUNCH_FAST(k_compress_fast, uint32_t, 2, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
+        else ZLZ4_LAUNCH_FAST(k_compress_fast, uint32_t, 0, wpw, wpw * 4096 * sizeof(uint32_t) + lds_pad);
     }
 #undef ZLZ4_LAUNCH_FAST
     return hipGetLastError() == hipSuccess ? 0 : -7;
