@@ -67,9 +67,19 @@ extern "C" {
 /* ======================================================================
  * 1. Single-buffer entry points, HOST pointers -- the names root.zig binds.
  *    Each stages the buffer to the current HIP device, runs the batch kernel
- *    on one block and copies the result back (PCIe-inclusive; use section 2
- *    for throughput).  Re-entrant like the reference (no global state besides
- *    the lazily created device context).
+ *    on one block and copies the result back (PCIe-inclusive).  Re-entrant
+ *    like the reference (no global state besides the lazily created device
+ *    context).
+ *
+ *    CORRECT, NOT FAST -- USE THE BATCH CALLS (section 2) OR THE FRAME CALLS
+ *    (section 3) FOR THROUGHPUT.  One block is one wavefront's serial chain:
+ *    a 64 KiB zlz4_compress_default call takes ~1.9 ms (912 windows of ~2 us,
+ *    measured on MI355X; the one-thread host port of the reference needs
+ *    0.2 ms), zlz4_decompress_safe ~1.0 ms, whatever the staging costs -- the
+ *    greedy parse of ONE block cannot be spread over the chip without changing
+ *    its output.  A program that loops over blocks through these calls gets
+ *    slower, not faster; hand the whole batch to zlz4_batch_* instead (65 536
+ *    blocks per call run at ~94 GiB/s compress / ~410 GiB/s decompress).
  * ====================================================================== */
 
 /* replaces lz4.compressBound, src/lz4.zig:80-83 (pure arithmetic, no device) */

@@ -25,6 +25,12 @@ for w in cfg2 cfg3 cfg4 cfg5; do
   python3 tools/pmc_summarize.py $out/pmc_$w > $out/pmc_$w/summary.txt
   echo "$w profiled"
 done
+for l in 2 12; do     # the other two HC strategies (own kernels, own traffic)
+  tools/prof_kernels.sh $tag/prof_cfg4_level$l --workload cfg4 --level $l --steps 2 --warmup 1 --no-cpu | grep -v "^{"
+  tools/pmc_run.sh $out/pmc_cfg4_level$l "fetch write" --workload cfg4 --level $l
+  python3 tools/pmc_summarize.py $out/pmc_cfg4_level$l > $out/pmc_cfg4_level$l/summary.txt
+  echo "cfg4 level $l profiled"
+done
 fi
 if [ "$part" = all ] || [ "$part" = tests ]; then
 python -m pytest tests -q -m gpu > $out/gpu_tests.txt 2>&1; tail -2 $out/gpu_tests.txt
