@@ -1014,24 +1014,55 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
                 if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return fail();
         return hipGetLastError() == hipSuccess ? 0 : -7;
     }
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += chunk) {
-        const uint32_t nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+    // search-every-position pipeline (levels 10-12, and the A/B switch).  The price-based parse of round r runs on the
+    // side stream beside K2 of round r + 1: the parse keeps its records in LDS and leaves the vector memory path alone,
+    // the search is all gathers.  K1 of round r + 1 goes FIRST (it needs a CU's whole LDS, and a CU that the parse's
+    // small workgroups keep refilling never has it free: K1 launched beside the parse waited 30-45 ms per round), so
+    // links and results both alternate between two halves of their areas:
+    //   stream: K1(0) K2(0) K1(1) | K2(1) K1(2) | K2(2) ...        side: parse(0) | parse(1) | ...
+    static const bool opt_no_overlap = zlz4_tune_env("ZLZ4_HC_NO_OVERLAP") != nullptr;
+    HcSideStream *side = (optimal && chunk >= 2u && nblocks > chunk / 2u && !opt_no_overlap) ? hc_side_stream() : nullptr;
+    const uint32_t sub = side ? chunk / 2u : chunk;
+    auto fail = [&](int rc) -> int { if (side) (void)hipStreamSynchronize(side->st); return rc; };
+    auto links_of = [&](uint32_t round) { return d_link + (uint64_t)(side ? (round & 1u) : 0u) * sub * stride; };
+    auto launch_k1 = [&](uint32_t round, uint32_t b0) {
+        const uint32_t nb = nblocks - b0 < sub ? nblocks - b0 : sub;
         hipLaunchKernelGGL((k_hc_build_links<T>), dim3(nb), dim3(64 * kLinkWaves), kHcTableSize * 4u + 4096u * sizeof(T) + 16u, stream, d_in, d_in_off,
-                           d_in_len, d_link, stride, b0, nb, max_in_len);
+                           d_in_len, links_of(round), stride, b0, nb, max_in_len);
+    };
+    uint32_t round = 0;
+    if (nblocks) launch_k1(0, 0);
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += sub, round++) {
+        const uint32_t nb = nblocks - b0 < sub ? nblocks - b0 : sub;
+        const uint32_t half = side ? (round & 1u) : 0u;
+        R *res = d_res + (uint64_t)half * sub * stride;
+        if (side && round >= 2u && hipStreamWaitEvent(stream, side->emitted[half], 0) != hipSuccess) return fail(-7);   // parse(round - 2) read this half
         // every position (the price-based parse of levels 10-12 looks results up everywhere; blocks > 64 KiB)
         // (one-wave workgroups: 376 / 401 / 416 ms for 64 / 128 / 256 threads on configs[3] -- the wavefronts of a
         //  workgroup finish at very different times and a four-wave workgroup keeps its slots until the last one is done)
         hipLaunchKernelGGL((k_hc_search<T, R>), dim3((np_max + 63u) / 64u, nb), dim3(64), 0, stream, d_in,
-                           d_in_off, d_in_len, d_link, stride, d_res, b0, nb, max_attempts, optimal ? 1 : 0, max_in_len);
+                           d_in_off, d_in_len, links_of(round), stride, res, b0, nb, max_attempts, optimal ? 1 : 0, max_in_len);
+        if (side && b0 + sub < nblocks) launch_k1(round + 1u, b0 + sub);      // (its half of the links was last read by K2(round - 1))
         if (optimal) {
-            const int rc = zlz4_launch_hc_opt_parse(stream, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
-                                                    d_res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len, max_in_len);
-            if (rc != 0) return rc;
+            hipStream_t parse_on = stream;
+            if (side) {
+                if (hipEventRecord(side->searched[half], stream) != hipSuccess ||
+                    hipStreamWaitEvent(side->st, side->searched[half], 0) != hipSuccess) return fail(-7);
+                parse_on = side->st;
+            }
+            const int rc = zlz4_launch_hc_opt_parse(parse_on, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result,
+                                                    res, stride, sizeof(R) == 8 ? 1 : 0, d_opt, b0, nb, sufficient_len, max_in_len);
+            if (rc != 0) return fail(rc);
+            if (side && hipEventRecord(side->emitted[half], side->st) != hipSuccess) return fail(-7);
         } else {
             hipLaunchKernelGGL((k_hc_parse_emit<R>), dim3((nb + 3u) / 4u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
-                               d_out, d_out_off, d_out_cap, d_result, d_res, stride, b0, nb, max_in_len);
+                               d_out, d_out_off, d_out_cap, d_result, res, stride, b0, nb, max_in_len);
         }
+        if (!side && b0 + sub < nblocks) launch_k1(round + 1u, b0 + sub);
     }
+    if (side)     // join
+        for (uint32_t k = 0; k < 2u && k < round; k++)
+            if (hipStreamWaitEvent(stream, side->emitted[k], 0) != hipSuccess) return fail(-7);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
 

@@ -378,6 +378,236 @@ __global__ __launch_bounds__(64) void k_hc_opt_parse(const uint8_t *__restrict__
     d_result[blk] = out;
 }
 
+
+// ------------------------------------------------------------------ levels 10-12, blocks <= 64 KiB: one WAVEFRONT per block
+// The price-based parse (compressOptimal, :1068-1391) is serial over the positions of its window, but what it does at a
+// position is not: the literal updates (:1260-1270), the price update over all match lengths (:1274-1302) and the
+// trailing literals (:1305-1311) touch up to 4095 independent records.  Here the wavefront walks the positions in
+// lock step (every scalar of the reference's loop is wave-uniform) and the lanes take the records: one LDS read and
+// one LDS write serve 64 match lengths.  opt[] lives in LDS as 8-byte records -- price 18 bits (<= 65 796 + the window's
+// own growth), offset 16, match length 13 (<= 4095), literal length 17 (<= 65 539): exact for blocks <= 64 KiB --
+// and only its first kOptLds records: the window of an ordinary block stays far below that, so 8 KiB per wavefront keep
+// 20 blocks per CU in flight where the whole array (32 KiB) would allow 4; records beyond go to the HBM array the
+// one-lane kernel uses (same values, 16-byte records).  The search results of 64 consecutive positions are held in
+// registers.  Same decisions in the same order as k_hc_opt_parse, including the reference's early-encode walk.
+constexpr uint32_t kOptLds = 1000;
+typedef __attribute__((address_space(3))) volatile uint64_t lds_opt;
+
+__device__ __forceinline__ uint64_t opt_pack(uint32_t price, uint32_t off, uint32_t mlen, uint32_t litlen) {
+    return (uint64_t)(price & 0x3FFFFu) | ((uint64_t)(off & 0xFFFFu) << 18) | ((uint64_t)(mlen & 0x1FFFu) << 34) |
+           ((uint64_t)(litlen & 0x1FFFFu) << 47);
+}
+__device__ __forceinline__ uint32_t opt_price(uint64_t e) { return (uint32_t)e & 0x3FFFFu; }
+__device__ __forceinline__ uint32_t opt_off(uint64_t e) { return (uint32_t)(e >> 18) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t opt_mlen(uint64_t e) { return (uint32_t)(e >> 34) & 0x1FFFu; }
+__device__ __forceinline__ uint32_t opt_litlen(uint64_t e) { return (uint32_t)(e >> 47); }
+
+// encodeSequence (:308-386) with limitedOutput by the whole wavefront (as in k_hc_parse_emit); false = does not fit
+__device__ __forceinline__ bool encode_sequence_wave(const uint8_t *src, uint8_t *dst, uint32_t oend, uint32_t &ip, uint32_t &op,
+                                                     uint32_t &anchor, uint32_t len, uint32_t off, uint32_t lane) {
+    const uint32_t lit = ip - anchor;                            // :317 (wraps like the reference's usize when ip < anchor)
+    if ((uint64_t)op + lit / 255u + lit + (2u + 1u + kLastLiterals) > oend) return false;       // :320-325
+    const uint32_t ml_code = len - kMinMatch;                    // :354
+    const uint32_t nle = ext_len_bytes(lit), nme = ext_len_bytes(ml_code);
+    const uint32_t op2 = op + 1u + nle + lit + 2u;
+    if ((uint64_t)op2 + ml_code / 255u + (1u + kLastLiterals) > oend) return false;             // :355-359
+    if (lane == 0) dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (ml_code >= 15u ? 15u : ml_code));
+    if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
+    copy_bytes(dst + op + 1u + nle, src + anchor, lit, lane);    // :346
+    if (lane < 2u) dst[op2 - 2u + lane] = (uint8_t)(off >> (8u * lane));   // :350
+    if (ml_code >= 15u) write_ext_len(dst + op2, ml_code, lane);           // :361-376
+    op = op2 + nme;
+    ip += len;                                                   // :382
+    anchor = ip;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_hc_opt_parse_wave(const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
+                                                          const uint32_t *__restrict__ d_in_len, uint8_t *__restrict__ d_out,
+                                                          const uint64_t *__restrict__ d_out_off,
+                                                          const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result,
+                                                          const uint32_t *__restrict__ d_res, uint64_t res_stride,
+                                                          OptEntry *__restrict__ d_opt, uint32_t blk0, uint32_t nblocks,
+                                                          uint32_t sufficient_len_in, uint32_t max_in_len) {
+    __shared__ uint64_t opt_lds_raw[kOptLds];
+    lds_opt *opt_l = (lds_opt *)opt_lds_raw;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t blk = blk0 + b;
+    const uint8_t *src = d_in + d_in_off[blk];
+    uint8_t *dst = d_out + d_out_off[blk];
+    const uint32_t n = rfl(d_in_len[blk]), oend = rfl(d_out_cap[blk]);
+    int64_t out;
+    if (n > kMaxInput) out = kErrInputTooLarge;
+    else if (n > max_in_len) out = kErrInvalidState;
+    else if (n == 0) out = 0;
+    else if (oend == 0) out = kErrOutputTooSmall;
+    else if (n < kMfLimit + 1u) {                                                 // :1092-1094
+        if (oend < n + 1u + n / 255u) out = kErrOutputTooSmall;
+        else {
+            if (lane == 0) dst[0] = (uint8_t)(n << 4);
+            if (lane < n) dst[1u + lane] = src[lane];
+            out = (int64_t)n + 1;
+        }
+    } else {
+        const uint32_t *res = d_res + (uint64_t)b * res_stride;
+        OptEntry *opt_g = d_opt + (uint64_t)b * kOptEntries;
+        const uint32_t mflimit = n - kMfLimit;
+        uint32_t sufficient_len = sufficient_len_in;                              // :1105-1108
+        if (sufficient_len >= kOptNum) sufficient_len = kOptNum - 1u;
+        // records: per-lane index (may differ between lanes)
+        auto get = [&](uint32_t idx) -> uint64_t {
+            if (idx < kOptLds) return opt_l[idx];
+            const OptEntry e = opt_g[idx];
+            return opt_pack((uint32_t)e.price, (uint32_t)e.off, (uint32_t)e.mlen, (uint32_t)e.litlen);
+        };
+        auto put = [&](uint32_t idx, uint64_t e) {
+            if (idx < kOptLds) opt_l[idx] = e;
+            else { OptEntry g; g.price = (int32_t)opt_price(e); g.off = (int32_t)opt_off(e); g.mlen = (int32_t)opt_mlen(e); g.litlen = (int32_t)opt_litlen(e); opt_g[idx] = g; }
+        };
+        // wave-uniform index: every lane reads the same record
+        auto get_u = [&](uint32_t idx) -> uint64_t {
+            const uint64_t e = get(idx);
+            return (uint64_t)rfl((uint32_t)e) | ((uint64_t)rfl((uint32_t)(e >> 32)) << 32);
+        };
+        // search results of 64 consecutive positions in registers
+        uint32_t wbase = 0;
+        uint32_t rw = res[lane];                                  // (the result array is padded past n)
+        auto best_match = [&](uint32_t p, uint32_t &len, uint32_t &off) {         // insertHC + insertAndGetWiderMatch result at p
+            if (p - wbase >= 64u) { wbase = p; rw = res[p + lane]; }
+            const uint32_t r = rdlane(rw, p - wbase);
+            len = r & 0xFFFFu; off = r >> 16;
+        };
+        uint32_t ip = 0, anchor = 0, op = 0;
+        bool failed = false;
+        uint32_t guard = 0;
+        while (ip <= mflimit && !failed) {                                        // :1111
+            if (++guard > 2u * n + 16u) { failed = true; break; }                 // unreachable; never spin on the GPU
+            const uint32_t llen = ip - anchor;
+            uint32_t first_len, first_off;
+            best_match(ip, first_len, first_off);                                 // :1115-1125
+            if (first_len == 0) { ip += 1; continue; }                            // :1127
+            if (first_len > sufficient_len) {                                     // :1133-1147
+                if (!encode_sequence_wave(src, dst, oend, ip, op, anchor, first_len, first_off, lane)) failed = true;
+                continue;
+            }
+            const uint32_t match_ml = first_len;                                  // :1160
+            for (uint32_t k = lane; k <= match_ml; k += 64u) {                    // :1150-1169
+                const uint64_t e = k < kMinMatch ? opt_pack((uint32_t)literals_price((int32_t)(llen + k)), 0u, 1u, llen + k)
+                                                 : opt_pack((uint32_t)sequence_price((int32_t)llen, (int32_t)k), first_off, k, llen);
+                put(k, e);
+            }
+            uint32_t last_match_pos = match_ml;                                   // :1171
+            {   // :1174-1180 (opt[last_match_pos].price is the price just written for ml == match_ml, or of a literal record)
+                const uint32_t base = match_ml < kMinMatch ? (uint32_t)literals_price((int32_t)(llen + match_ml))
+                                                           : (uint32_t)sequence_price((int32_t)llen, (int32_t)match_ml);
+                if (lane >= 1u && lane <= kTrailingLiterals)
+                    put(last_match_pos + lane, opt_pack(base + (uint32_t)literals_price((int32_t)lane), 0u, 1u, lane));
+            }
+            bool encoded_early = false;
+            for (uint32_t cur = 1; cur < last_match_pos; cur++) {                 // :1183-1312
+                const uint32_t cur_pos = ip + cur;
+                if (cur_pos > mflimit) break;                                     // :1187
+                const uint64_t ec = get_u(cur), en = get_u(cur + 1u);
+                if (opt_price(en) <= opt_price(ec)) continue;                     // :1190
+                uint32_t new_len, new_off;
+                best_match(cur_pos, new_len, new_off);                            // :1193-1203
+                if (new_len == 0) continue;                                       // :1205
+                if ((new_len > sufficient_len) || (new_len + cur >= kOptNum)) {   // :1208
+                    uint32_t rp = 0;                                              // :1216-1238 (forward walk, no reverse traversal)
+                    while (rp < cur) {
+                        const uint64_t e = get_u(rp);
+                        const uint32_t ml = opt_mlen(e), off = opt_off(e);
+                        if (ml == 1u) { ip += 1; rp += 1; continue; }
+                        rp += ml;
+                        if (!encode_sequence_wave(src, dst, oend, ip, op, anchor, ml, off, lane)) { failed = true; break; }
+                    }
+                    if (!failed && !encode_sequence_wave(src, dst, oend, ip, op, anchor, new_len, new_off, lane)) failed = true;   // :1241-1252
+                    encoded_early = true;                                         // :1255
+                    break;
+                }
+                const uint32_t base_litlen = opt_litlen(ec);                      // :1259
+                const uint32_t pc = opt_price(ec);
+                // :1276-1286 what a match that starts here costs before its own sequence price
+                uint32_t ll, pb;
+                if (opt_mlen(ec) == 1u) {
+                    ll = base_litlen;
+                    pb = cur > ll ? opt_price(get_u(cur - ll)) : 0u;
+                } else {
+                    ll = 0; pb = pc;
+                }
+                const uint32_t lit_base = pc - (uint32_t)literals_price((int32_t)base_litlen);
+                // :1260-1302 in one pass: record cur + k for k = 1 .. max(3, new_len); k < 4 are the literal updates
+                const uint32_t kmax = new_len > 3u ? new_len : 3u;
+                bool grew = false;
+                for (uint32_t k0 = 1; k0 <= kmax; k0 += 64u) {
+                    const uint32_t k = k0 + lane;
+                    const bool act = k <= kmax;
+                    const uint32_t pos = cur + k;
+                    const uint64_t old = act ? get(pos) : 0ull;
+                    if (act) {
+                        if (k < kMinMatch) {
+                            const uint32_t price = lit_base + (uint32_t)literals_price((int32_t)(base_litlen + k));
+                            if ((int32_t)price < (int32_t)opt_price(old)) put(pos, opt_pack(price, 0u, 1u, base_litlen + k));
+                        } else {
+                            const uint32_t price = pb + (uint32_t)sequence_price((int32_t)ll, (int32_t)k);
+                            if (pos > last_match_pos + kTrailingLiterals || (int32_t)price <= (int32_t)opt_price(old)) {   // :1293
+                                put(pos, opt_pack(price, new_off, k, ll));
+                                if (k == new_len) grew = true;
+                            }
+                        }
+                    }
+                }
+                if (ballot(grew) && last_match_pos < cur + new_len) last_match_pos = cur + new_len;   // :1294
+                {   // :1305-1311
+                    const uint32_t base = opt_price(get_u(last_match_pos));
+                    if (lane >= 1u && lane <= kTrailingLiterals)
+                        put(last_match_pos + lane, opt_pack(base + (uint32_t)literals_price((int32_t)lane), 0u, 1u, lane));
+                }
+            }
+            if (encoded_early || failed) continue;
+            {   // reverse traversal (:1315-1332)
+                const uint64_t el = get_u(last_match_pos);
+                uint32_t sel_ml = opt_mlen(el), sel_off = opt_off(el);
+                uint32_t cand = last_match_pos - sel_ml;
+                for (;;) {
+                    const uint64_t e = get_u(cand);
+                    const uint32_t next_ml = opt_mlen(e), next_off = opt_off(e);
+                    if (lane == 0) put(cand, opt_pack(opt_price(e), sel_off, sel_ml, opt_litlen(e)));
+                    sel_ml = next_ml; sel_off = next_off;
+                    if (next_ml > cand) break;
+                    cand -= next_ml;
+                }
+            }
+            uint32_t rp = 0;                                                      // :1335-1358
+            while (rp < last_match_pos) {
+                const uint64_t e = get_u(rp);
+                const uint32_t ml = opt_mlen(e), off = opt_off(e);
+                if (ml == 1u) { ip += 1; rp += 1; continue; }
+                rp += ml;
+                if (!encode_sequence_wave(src, dst, oend, ip, op, anchor, ml, off, lane)) { failed = true; break; }
+            }
+        }
+        if (failed) out = kErrOutputTooSmall;
+        else {
+            const uint32_t fl = n - anchor;                                       // :1362-1388
+            out = (int64_t)op;
+            if (fl > 0) {
+                const uint32_t nle = ext_len_bytes(fl);
+                if ((uint64_t)op + fl + 1u > oend || (uint64_t)op + 1u + nle + fl > oend) out = kErrOutputTooSmall;
+                else {
+                    if (lane == 0) dst[op] = (uint8_t)((fl >= 15u ? 15u : fl) << 4);
+                    if (fl >= 15u) write_ext_len(dst + op + 1u, fl, lane);
+                    copy_bytes(dst + op + 1u + nle, src + anchor, fl, lane);
+                    out = (int64_t)(op + 1u + nle + fl);
+                }
+            }
+        }
+    }
+    if (lane == 0) d_result[blk] = out;
+}
+
 }  // namespace zlz4
 
 extern "C" size_t zlz4_hc_mid_workspace_bytes(uint32_t chunk_blocks) {
@@ -409,6 +639,15 @@ extern "C" int zlz4_launch_hc_opt_parse(hipStream_t stream, const uint8_t *d_in,
                                         int wide, void *d_opt, uint32_t b0, uint32_t nb, uint32_t sufficient_len,
                                         uint32_t max_in_len) {
     static const uint32_t lanes = [] { const char *e = zlz4_tune_env("ZLZ4_OPT_LANES"); const uint32_t v = e ? (uint32_t)atoi(e) : 1u; return v >= 1u && v <= 64u ? v : 1u; }();
+    // blocks <= 64 KiB: one wavefront per block, the lanes take the records of a position's price update (A/B switch for
+    // profiles/: ZLZ4_OPT_WAVE=0 in the tuning build = the one-lane kernel)
+    static const bool wave = [] { const char *e = zlz4_tune_env("ZLZ4_OPT_WAVE"); return !(e && atoi(e) == 0); }();
+    if (!wide && wave) {
+        hipLaunchKernelGGL(zlz4::k_hc_opt_parse_wave, dim3(nb), dim3(64), 0, stream, d_in, d_in_off, d_in_len, d_out, d_out_off,
+                           d_out_cap, d_result, static_cast<const uint32_t *>(d_res), res_stride,
+                           static_cast<zlz4::OptEntry *>(d_opt), b0, nb, sufficient_len, max_in_len);
+        return hipGetLastError() == hipSuccess ? 0 : -7;
+    }
     if (wide)
         hipLaunchKernelGGL(zlz4::k_hc_opt_parse<uint64_t>, dim3((nb + lanes - 1u) / lanes), dim3(lanes), 0, stream, d_in, d_in_off, d_in_len,
                            d_out, d_out_off, d_out_cap, d_result, static_cast<const uint64_t *>(d_res), res_stride,
