@@ -33,7 +33,8 @@ extern "C" {
 #define ZLZ4_ERR_ALLOCATION_FAILED     (-6)
 /* ---- new in this library ---- */
 #define ZLZ4_ERR_DEVICE                (-7)   /* HIP runtime / no gfx950 device / launch failure */
-#define ZLZ4_ERR_UNSUPPORTED           (-8)   /* reserved: a request the device path cannot serve (none at present) */
+#define ZLZ4_ERR_UNSUPPORTED           (-8)   /* a request the device path cannot serve (content checksum of a split frame) */
+#define ZLZ4_ERR_VERIFY                (-9)   /* zlz4_batch_verify: the compressed block does not decode back to its input */
 
 /* ---- lz4f.Error (src/lz4f.zig:31-55): -(100 + 1-based declaration index) ---- */
 #define ZLZ4F_ERR_GENERIC                   (-101)
@@ -174,6 +175,19 @@ int32_t zlz4_batch_compress_hc(void *stream,
                                uint8_t *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
                                int64_t *d_result, uint32_t nblocks, uint32_t max_in_len,
                                int32_t compression_level, void *d_workspace, size_t workspace_bytes);
+
+/* Opt-in check for the levels whose output the reference itself does not always get right (10..12, see the HAZARD note
+ * at zlz4_compress_hc): decodes every compressed block on the device and compares it with its input.
+ *   d_comp_result[i] : what the compress call wrote for block i (size, or a negative code, which is passed through)
+ *   d_verify[i]      : receives d_comp_result[i] if the block decodes back to its d_in_len[i] input bytes,
+ *                      ZLZ4_ERR_VERIFY if it does not
+ * Returns the number of blocks that failed the check (0 = all good), or ZLZ4_ERR_*.  Unlike the calls above this one
+ * allocates its scratch memory itself (a decode arena as large as the input) and synchronises `stream` before returning;
+ * it is a safety net, not part of the hot path.  No counterpart in the reference. */
+int64_t zlz4_batch_verify(void *stream,
+                          const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                          const uint8_t *d_comp, const uint64_t *d_comp_off, const int64_t *d_comp_result,
+                          int64_t *d_verify, uint32_t nblocks);
 
 /* ======================================================================
  * 3. Frame container (src/lz4f.zig), HOST pointers.

@@ -103,3 +103,42 @@ def test_cpp_host_mirror_gpu_branch(zl, gpu, tmp_path):
     print(out.stdout)
     assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr
     assert "batch" in out.stdout, "the GPU branch did not run: " + out.stdout
+
+
+def test_batch_verify_flags_the_streams_that_do_not_round_trip(zl, oracle, gpu):
+    """zlz4_batch_verify (the opt-in safety net for levels 10..12, include/zlz4_amd.h): level 9 streams all verify; at
+    level 10 the blocks whose reference stream does not decode to the input (the oracle's own decoder decides) are
+    flagged with ZLZ4_ERR_VERIFY and the others are not; negative compress results pass through."""
+    import torch
+    items = [bytes(dg.text_bytes(n, 300 + i)) for i, n in enumerate((65536, 40000, 65536, 3000, 65536, 12, 0, 65536))]
+    for level in (9, 10):
+        buf, offs, lens = gh._pack(items)
+        caps = np.array([zl.compressBound(len(b)) for b in items], dtype=np.int64)
+        caps[3] = 20                                            # one block that cannot fit: OutputTooSmall passes through
+        out_offs = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16 + 64)[:-1]]).astype(np.int64)
+        d_in = torch.from_numpy(buf).to(gpu)
+        d_out = torch.zeros(int(out_offs[-1] + caps[-1] + 80), dtype=torch.uint8, device=gpu)
+        res = torch.full((len(items),), -999, dtype=torch.int64, device=gpu)
+        t_off, t_len = torch.from_numpy(offs).to(gpu), torch.from_numpy(lens.astype(np.uint32).view(np.int32)).to(gpu)
+        t_ooff, t_cap = torch.from_numpy(out_offs).to(gpu), torch.from_numpy(caps.astype(np.uint32).view(np.int32)).to(gpu)
+        ws = torch.empty(max(16, zl.batch_compress_hc_workspace(len(items), 65536)), dtype=torch.uint8, device=gpu)
+        zl.batch_compress_hc(d_in, t_off, t_len, d_out, t_ooff, t_cap, res, 65536, level, ws)
+        ver = torch.full((len(items),), -777, dtype=torch.int64, device=gpu)
+        nbad = zl.batch_verify(d_in, t_off, t_len, d_out, t_ooff, res, ver)
+        r, v, o = res.cpu().numpy(), ver.cpu().numpy(), d_out.cpu().numpy()
+        want_bad = 0
+        for i, b in enumerate(items):
+            if r[i] < 0:
+                assert v[i] == r[i], (level, i, r[i], v[i])
+                continue
+            stream = bytes(o[out_offs[i]: out_offs[i] + r[i]])
+            dec = oracle.decompress_safe(stream, len(b))
+            good = (not isinstance(dec, int)) and dec == b
+            want_bad += 0 if good else 1
+            assert v[i] == (r[i] if good else -9), (level, i, r[i], v[i], good)
+        assert nbad == want_bad, (level, nbad, want_bad)
+        assert r[3] == -1
+        if level == 9:
+            assert nbad == 0
+        else:
+            assert nbad > 0, "level 10 is expected to lose ordinary 64 KiB text blocks (DESIGN.md section 2)"

@@ -69,6 +69,7 @@ SYMBOLS = {
     "zlz4_batch_decompress_safe": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32]),
     "zlz4_batch_compress_hc_workspace": (_SZ, [_U32, _U32]),
     "zlz4_batch_compress_hc": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _U32, _I32, _VP, _SZ]),
+    "zlz4_batch_verify": (_I64, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32]),
     "zlz4f_compress_frame_bound": (_SZ, [_SZ, _PP]),
     "zlz4f_compress_frame": (_I64, [_VP, _SZ, _VP, _SZ, _PP]),
     "zlz4f_decompress_frame": (_I64, [_VP, _SZ, _VP, _SZ]),
@@ -288,3 +289,10 @@ def batch_compress_hc(d_in, in_off, in_len, d_out, out_off, out_cap, result, max
     _check(lib().zlz4_batch_compress_hc(_stream(), _ptr(d_in), _ptr(in_off), _ptr(in_len), _ptr(d_out),
                                         _ptr(out_off), _ptr(out_cap), _ptr(result), in_len.numel(), max_in_len,
                                         level, _ptr(workspace), workspace.numel()))
+
+
+def batch_verify(d_in, in_off, in_len, d_comp, comp_off, comp_result, verify):
+    """zlz4_batch_verify: decode every compressed block on the device and compare with its input; returns the number of
+    blocks that do not round-trip (verify[i] = the compress result, or ZLZ4_ERR_VERIFY = -9)."""
+    return _check(lib().zlz4_batch_verify(_stream(), _ptr(d_in), _ptr(in_off), _ptr(in_len), _ptr(d_comp), _ptr(comp_off),
+                                          _ptr(comp_result), _ptr(verify), in_len.numel()))

@@ -127,6 +127,7 @@ const char *zlz4_error_name(int64_t code) {
         case ZLZ4_ERR_ALLOCATION_FAILED: return "AllocationFailed";
         case ZLZ4_ERR_DEVICE: return "DeviceError";
         case ZLZ4_ERR_UNSUPPORTED: return "Unsupported";
+        case ZLZ4_ERR_VERIFY: return "VerifyFailed";
         case ZLZ4F_ERR_GENERIC: return "Generic";
         case ZLZ4F_ERR_MAX_BLOCK_SIZE_INVALID: return "MaxBlockSizeInvalid";
         case ZLZ4F_ERR_BLOCK_MODE_INVALID: return "BlockModeInvalid";
@@ -350,4 +351,83 @@ int32_t zlz4_batch_compress_hc(void *stream, const uint8_t *d_in, const uint64_t
                                    d_result, nblocks, max_in_len, level, d_workspace, workspace_bytes);
 }
 
+// ---------------------------------------------------------------- opt-in round-trip check (levels 10..12)
 }  // extern "C"
+
+namespace {
+// decode descriptors from the compress results: length 0 for a block that reported an error, capacity = the input length
+__global__ void k_verify_prep(const int64_t *__restrict__ comp_result, const uint32_t *__restrict__ in_len,
+                              const uint64_t *__restrict__ in_off, uint64_t base_off, uint32_t *__restrict__ clen,
+                              uint64_t *__restrict__ dec_off, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = comp_result[i];
+    clen[i] = r > 0 ? (uint32_t)r : 0u;
+    dec_off[i] = in_off[i] - base_off;
+    (void)in_len;
+}
+// one wavefront per block: decoded size and bytes against the input
+__global__ __launch_bounds__(256) void k_verify_compare(const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ in_off,
+                                                        const uint32_t *__restrict__ in_len, const uint8_t *__restrict__ d_dec,
+                                                        const uint64_t *__restrict__ dec_off, const int64_t *__restrict__ dec_result,
+                                                        const int64_t *__restrict__ comp_result, int64_t *__restrict__ verify,
+                                                        unsigned long long *__restrict__ nbad, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t cr = comp_result[i];
+    int64_t out = cr;
+    if (cr >= 0) {
+        const uint32_t len = in_len[i];
+        bool bad = dec_result[i] != (int64_t)len && !(len == 0 && cr == 0);
+        if (!bad) {
+            const uint8_t *a = d_in + in_off[i], *b = d_dec + dec_off[i];
+            bool diff = false;
+            for (uint32_t k = lane; k < len; k += 64u) diff |= a[k] != b[k];
+            bad = __ballot(diff) != 0;
+        }
+        if (bad) out = ZLZ4_ERR_VERIFY;
+    }
+    if (lane == 0) {
+        verify[i] = out;
+        if (out == ZLZ4_ERR_VERIFY) atomicAdd(nbad, 1ull);
+    }
+}
+}  // namespace
+
+extern "C" int64_t zlz4_batch_verify(void *stream, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                     const uint8_t *d_comp, const uint64_t *d_comp_off, const int64_t *d_comp_result,
+                                     int64_t *d_verify, uint32_t nblocks) {
+    if (!device_ok()) return ZLZ4_ERR_DEVICE;
+    if (nblocks == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    // the extent of the input arena (descriptors come back to the host: this call synchronises anyway)
+    std::vector<uint64_t> off(nblocks);
+    std::vector<uint32_t> len(nblocks);
+    if (hipMemcpyAsync(off.data(), d_in_off, nblocks * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(len.data(), d_in_len, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t i = 0; i < nblocks; i++) {
+        if (off[i] < lo) lo = off[i];
+        if (off[i] + len[i] > hi) hi = off[i] + len[i];
+    }
+    DeviceCall call(st);
+    DevBuf d_dec((size_t)(hi - lo) + 64, &call), d_clen((size_t)nblocks * 4, &call), d_doff((size_t)nblocks * 8, &call),
+        d_dres((size_t)nblocks * 8, &call), d_nbad(8, &call);
+    if (!d_dec.p || !d_clen.p || !d_doff.p || !d_dres.p || !d_nbad.p) return ZLZ4_ERR_ALLOCATION_FAILED;
+    call.launched();
+    if (hipMemsetAsync(d_nbad.p, 0, 8, st) != hipSuccess) return ZLZ4_ERR_DEVICE;
+    hipLaunchKernelGGL(k_verify_prep, dim3((nblocks + 255) / 256), dim3(256), 0, st, d_comp_result, d_in_len, d_in_off, lo,
+                       d_clen.as<uint32_t>(), d_doff.as<uint64_t>(), nblocks);
+    const int rc = zlz4_launch_decompress_safe(st, d_comp, d_comp_off, d_clen.as<uint32_t>(), d_dec.as<uint8_t>(),
+                                               d_doff.as<uint64_t>(), d_in_len, d_dres.as<int64_t>(), nblocks);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(k_verify_compare, dim3((nblocks + 3) / 4), dim3(256), 0, st, d_in, d_in_off, d_in_len, d_dec.as<uint8_t>(),
+                       d_doff.as<uint64_t>(), d_dres.as<int64_t>(), d_comp_result, d_verify,
+                       d_nbad.as<unsigned long long>(), nblocks);
+    unsigned long long nbad = 0;
+    if (hipMemcpyAsync(&nbad, d_nbad.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || !call.sync() ||
+        hipGetLastError() != hipSuccess) return ZLZ4_ERR_DEVICE;
+    return (int64_t)nbad;
+}

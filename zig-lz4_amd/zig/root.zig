@@ -26,6 +26,7 @@ extern "c" fn zlz4_batch_compress_fast(stream: ?*anyopaque, d_in: [*]const u8, d
 extern "c" fn zlz4_batch_decompress_safe(stream: ?*anyopaque, d_in: [*]const u8, d_in_off: [*]const u64, d_in_len: [*]const u32, d_out: [*]u8, d_out_off: [*]const u64, d_out_cap: [*]const u32, d_result: [*]i64, nblocks: u32) i32;
 extern "c" fn zlz4_batch_compress_hc_workspace(nblocks: u32, max_in_len: u32) usize;
 extern "c" fn zlz4_batch_compress_hc(stream: ?*anyopaque, d_in: [*]const u8, d_in_off: [*]const u64, d_in_len: [*]const u32, d_out: [*]u8, d_out_off: [*]const u64, d_out_cap: [*]const u32, d_result: [*]i64, nblocks: u32, max_in_len: u32, level: i32, d_workspace: ?*anyopaque, workspace_bytes: usize) i32;
+extern "c" fn zlz4_batch_verify(stream: ?*anyopaque, d_in: [*]const u8, d_in_off: [*]const u64, d_in_len: [*]const u32, d_comp: [*]const u8, d_comp_off: [*]const u64, d_comp_result: [*]const i64, d_verify: [*]i64, nblocks: u32) i64;
 
 pub const CPrefs = extern struct {
     block_size_id: u32 = 0,
@@ -178,6 +179,11 @@ pub const device = struct {
     /// batch form of compressHC (src/lz4hc.zig:1440-1453); `workspace` = device memory of compressHCWorkspace() bytes
     pub fn compressHCBatch(stream: ?*anyopaque, b: Blocks, max_in_len: u32, level: i32, workspace: ?*anyopaque, workspace_bytes: usize) Error!void {
         return mapLaunch(zlz4_batch_compress_hc(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.out_cap, b.result, b.nblocks, max_in_len, level, workspace, workspace_bytes));
+    }
+    /// opt-in check for levels 10..12 (include/zlz4_amd.h): decodes the batch a compress call produced (`b` as passed to
+    /// it) and compares with the input; verify[i] = b.result[i] or -9; returns the number of blocks that do not round-trip
+    pub fn verifyBatch(stream: ?*anyopaque, b: Blocks, verify: [*]i64) Error!usize {
+        return mapBlock(zlz4_batch_verify(stream, b.in, b.in_off, b.in_len, b.out, b.out_off, b.result, verify, b.nblocks));
     }
 };
 
