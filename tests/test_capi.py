@@ -152,5 +152,5 @@ def test_zig_facade_declares_the_reference_names():
         assert frag in txt, frag
     import zig_lz4_amd
     L = zig_lz4_amd.lib()
-    for fn in set(re.findall(r"extern (?:"c" )?fn (zlz4f?_\w+)\(", txt)):
+    for fn in set(re.findall(r'extern (?:"c" )?fn (zlz4f?_\w+)\(', txt)):
         assert hasattr(L, fn), "root.zig binds %s, which the library does not export" % fn
