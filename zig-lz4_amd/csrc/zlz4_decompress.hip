@@ -52,11 +52,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 // decompressed size before placing the blocks (lz4f.decompressFrame accumulates dstPos serially).
 // kLaneCopy: short matches are moved four bytes per lane (batches that fill the chip); false = 16 bytes per sequence lane
 // for every match (few blocks: the shorter latency chain)
-template <bool kWrite, bool kLaneCopy = false>
+// (eight wavefronts per SIMD = at most 64 VGPRs: the copy phases brought the lane-copy build to 66, and the seventh of eight
+//  wavefronts cost D-text 7 % -- the decoder is bound by vector issue and lives on occupancy)
+template <bool kWrite, bool kLaneCopy = false, bool kPhases = kLaneCopy>
+#ifdef ZLZ4_DEC_NO_WPE
 __global__ __launch_bounds__(256) void k_decompress_safe(
+#else
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decompress_safe(
+#endif
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
-    const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks) {
+    const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t min_phase_tokens) {
     constexpr uint32_t short_max = kLaneCopy ? 32u : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t blk = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -84,16 +90,15 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
         // Matches of <= 32 bytes (nearly all of a batch) are moved four bytes per lane, eight lanes per sequence: ONE dword
         // load and ONE dword store serve eight sequences, where a 16-byte move per sequence lane costs the CU's address
         // path four times the cycles per instruction for an eighth of the lanes.  pd = the lane's piece, pdo = where it
-        // goes (kNone = nothing pending); up to three rounds of eight sequences per batch.
+        // goes (kNone = nothing pending); two rounds of eight sequences per phase (a phase is cut after its 16th short match).
         constexpr uint32_t kNone = 0xFFFFFFFFu;
-        uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pdo0 = kNone, pdo1 = kNone, pdo2 = kNone;
+        uint32_t pd0 = 0, pd1 = 0, pdo0 = kNone, pdo1 = kNone;
         auto flush_pending = [&]() {
             if (!kWrite) return;
             if constexpr (kLaneCopy) {
                 if (pdo0 != kNone) __builtin_memcpy(dst + pdo0, &pd0, 4);
                 if (pdo1 != kNone) __builtin_memcpy(dst + pdo1, &pd1, 4);
-                if (pdo2 != kNone) __builtin_memcpy(dst + pdo2, &pd2, 4);
-                pdo0 = pdo1 = pdo2 = kNone;
+                pdo0 = pdo1 = kNone;
             }
             if (pml != 0) {
                 // (every address is dst + a 32-bit offset: the uniform base stays in scalar registers and no lane
@@ -258,14 +263,19 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     : "scc");
                 DSTAMP(1);
                 uint32_t relv = 0;
+                const uint64_t R_walk = R;                          // every token the walk took
+                const uint32_t T_walk = T, pos_walk = pos;
+                bool viol_err = false;                              // :181-186 / :231 offset > op: never copied here
+                const uint32_t op0 = op;                            // output position of the batch
                 if (R != 0) {
                     const bool real0 = (R >> lane) & 1ull;
                     const uint32_t x = real0 ? ol : 0u;
                     relv = wave_incl_scan(x) - x;                   // output offset of the sequence inside the batch
                     // :181-186 / :231 offset > op, and (copy pass) a match source that reaches into this batch's
-                    // matches: end the batch in front of the first such sequence
+                    // matches: end the phase in front of the first such sequence
                     const uint32_t lit0 = rdlane(lit, 0);
-                    bool viol = off > op + relv + lit;
+                    viol_err = off > op0 + relv + lit;
+                    bool viol = viol_err;
                     if (kWrite) viol = viol || (off + lit0 < relv + ol);
                     const uint64_t vm = ballot(real0 && viol);
                     if (vm != 0) {
@@ -278,11 +288,33 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 DSTAMP(2);
                 // The one wait of a batch: the window load issued at the top of this iteration and the match loads of
                 // the previous batch have had the whole parse / walk / scan to arrive.
-                asm volatile("s_waitcnt vmcnt(1)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(tdummy));
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(tdummy));
                 if (R == 0) break;                                  // the single-sequence paths take this one
                 DSTAMP_ADD(8, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
+                // A batch is copied in PHASES.  The match loads of a phase are issued with it and stored when the next
+                // one begins, so a match whose source reaches into the output of an earlier match of the same phase ends
+                // the phase in front of it -- but not the batch: everything the parse side found out about the window
+                // (160 of a batch's 200 vector instructions) still holds, so the rest of the walk's tokens simply form the
+                // next phase, which costs a wait for the previous phase's loads, their stores and the copy side again.
+                // (Repetitive text -- a word that comes back within ~100 bytes -- had 3.9 sequences per batch against 8.)
+                // the lane-copy registers hold two rounds of eight short matches: a phase with more is cut after the 16th
+                // (what is left is the next phase, or the next batch)
+                auto cap_short = [&]() {
+                    if constexpr (kWrite && kLaneCopy) {
+                        const bool sh = ((R >> lane) & 1ull) && ml <= short_max;
+                        const uint64_t S = ballot(sh);
+                        if ((uint32_t)__popcll(S) > 16u) {
+                            const uint32_t rk = (uint32_t)__popcll(S & ((1ull << lane) - 1ull));
+                            const uint32_t fb = first_lane(ballot(sh && rk == 16u));
+                            R &= (1ull << fb) - 1ull;
+                            T = rdlane(relv, fb);
+                            pos = fb;
+                        }
+                    }
+                };
+                auto copy_side = [&]() {
                 if (kWrite) {
-                    flush_pending();                                // the previous batch's match stores
+                    flush_pending();                                // the previous phase's / batch's match stores
                     DSTAMP(7);
                     // literals (:140): window byte x belongs to the last token at or before x
                     const uint64_t below = R & (~0ull >> (63u - lane));
@@ -290,13 +322,13 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     const uint32_t q = shfl(relv | (lit << 16), kl);
                     const uint32_t qlit = q >> 16;
                     const uint32_t d = lane - kl - (qlit >= 15u ? 2u : 1u);
-                    if (d < qlit) dst[op + (q & 0xFFFFu) + d] = (uint8_t)b0;
+                    if (d < qlit && below != 0) dst[op0 + (q & 0xFFFFu) + d] = (uint8_t)b0;
                     DSTAMP(3);
-                    // matches (:244): source entirely older than this batch's first match, no overlap.  One or two
+                    // matches (:244): source entirely older than this phase's first match, no overlap.  One or two
                     // 16-byte loads per sequence lane; the data is stored by flush_pending() after the next batch
-                    // has been parsed.
+                    // has been parsed (or when the next phase begins).
                     const bool real = (R >> lane) & 1ull;
-                    const uint32_t po_t = op + relv + lit, mo_t = po_t - off;       // (off <= 65535, ml <= 273)
+                    const uint32_t po_t = op0 + relv + lit, mo_t = po_t - off;      // (off <= 65535, ml <= 273)
                     // short_max = 32 when the chip is full (the address path is what bounds the kernel then), 0 with few
                     // blocks (one wavefront per SIMD: the permutes are four more dependent steps of a latency chain, and
                     // 16 bytes per sequence lane is the shorter chain: 38.3 against 43.4 ms on 1024 x 4 MiB)
@@ -334,9 +366,41 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                         };
                         round(0u, pd0, pdo0);
                         if (ns > 8u) round(8u, pd1, pdo1);
-                        if (ns > 16u) round(16u, pd2, pdo2);
                     }
                     DSTAMP(4);
+                }
+                };
+                cap_short();
+                copy_side();
+                // ---- further phases: only the copy pass has them, only if the phase before was cut short, only while
+                //      enough tokens are left to pay for a phase (it costs about half a batch; a batch that lost its last
+                //      token or two is better off starting the next batch there), and only while the token that cut it can
+                //      itself be copied (no :181 error, no overlap with its own output) ----
+                if constexpr (kWrite && kPhases) {
+                    for (uint32_t phase = 1; phase < 6u && pos != pos_walk; phase++) {
+                        const uint32_t first = pos, tbase = T;      // first token (lane) / output offset of the new phase
+                        const uint64_t Rn = R_walk & ~((1ull << first) - 1ull);
+                        if ((uint32_t)__builtin_popcountll(Rn) < min_phase_tokens) break;
+                        const bool realn = (Rn >> lane) & 1ull;
+                        const uint32_t lit_f = rdlane(lit, first);
+                        const bool violn = viol_err || (off + lit_f < (relv - tbase) + ol);
+                        const uint64_t vmn = ballot(realn && violn);
+                        if ((vmn >> first) & 1ull) break;           // single-sequence path for that token
+                        if (vmn != 0) {
+                            const uint32_t fb = first_lane(vmn);
+                            R = Rn & ((1ull << fb) - 1ull);
+                            T = rdlane(relv, fb);
+                            pos = fb;
+                        } else {
+                            R = Rn; T = T_walk; pos = pos_walk;
+                        }
+                        DSTAMP_ADD(12, 1); DSTAMP_ADD(9, __builtin_popcountll(R));
+                        // the loads of the phase before must have landed before flush_pending() stores them (right in front
+                        // of the copy side: every way into it passes this wait -- tools/check_decoder_asm.py)
+                        cap_short();
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(tdummy), "+v"(X2));
+                        copy_side();
+                    }
                 }
                 op += T;
                 ip += pos;
@@ -350,7 +414,7 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                     asm volatile("global_load_ubyte %0, %1, %2" : "+v"(tdummy) : "v"(toff), "s"(src) : "memory");
                 }
               }
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(tdummy));
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(X2), "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(tdummy));
               if (ip >= iend) { flush_pending(); break; }
             }
             flush_pending();
@@ -636,12 +700,19 @@ extern "C" int zlz4_launch_decompress_safe(hipStream_t stream, const uint8_t *d_
     // short matches four bytes per lane once the batch fills the chip (see the kernel); ZLZ4_DECOMP_SHORT forces 0 / 32
     static const int short_env = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_SHORT"); return e ? atoi(e) : -1; }();
     const uint32_t short_max = short_env >= 0 ? (uint32_t)short_env : (nblocks >= kLaneCopyMinBlocks ? 32u : 0u);
-    if (short_max)
+    // A/B switch for profiles/ (tuning build): the lane-copy decoder without copy phases
+    static const bool no_phases = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_PHASES"); return e && atoi(e) == 0; }();
+    // tokens that must be left for another copy phase to be worth its wait (ZLZ4_DECOMP_PHASE_MIN in the tuning build)
+    static const uint32_t min_phase_tokens = [] { const char *e = zlz4_tune_env("ZLZ4_DECOMP_PHASE_MIN"); return e ? (uint32_t)atoi(e) : 3u; }();
+    if (short_max && no_phases)
+        hipLaunchKernelGGL((zlz4::k_decompress_safe<true, true, false>), dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in,
+                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, min_phase_tokens);
+    else if (short_max)
         hipLaunchKernelGGL((zlz4::k_decompress_safe<true, true>), dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in,
-                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, min_phase_tokens);
     else
         hipLaunchKernelGGL((zlz4::k_decompress_safe<true, false>), dim3(grid), dim3(64 * waves_per_wg), dyn_lds, stream, d_in,
-                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks);
+                           d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_result, nblocks, min_phase_tokens);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
 
@@ -653,7 +724,7 @@ extern "C" int zlz4_launch_decompress_sizes(hipStream_t stream, const uint8_t *d
     const uint32_t waves_per_wg = 4;
     const uint32_t grid = (nblocks + waves_per_wg - 1) / waves_per_wg;
     hipLaunchKernelGGL((zlz4::k_decompress_safe<false, false>), dim3(grid), dim3(64 * waves_per_wg), 0, stream, d_in, d_in_off,
-                       d_in_len, (uint8_t *)nullptr, d_out_off, d_out_cap, d_result, nblocks);
+                       d_in_len, (uint8_t *)nullptr, d_out_off, d_out_cap, d_result, nblocks, 0u);
     return hipGetLastError() == hipSuccess ? 0 : -7;
 }
 
