@@ -406,11 +406,11 @@ def main():
         dec_gibs = total_n / (td_ms * 1e-3) / GIB
         hc_kernels = ("zlz4::k_hc_mid_serial" if args.level <= 2 else
                       "HC pipeline: k_hc_build_links + k_hc_seg_search<4> + k_hc_parse_emit (rounds of 4096 blocks, emit beside the next round)" if args.level <= 9 else
-                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse (rounds of 8192 blocks)")
+                      "HC pipeline: k_hc_build_links + k_hc_search + k_hc_opt_parse_wave (rounds of 4096 blocks, parse beside the next round's search)")
         # the decoder has two builds: lane-per-dword match copies for batches that fill the chip, 16 bytes per sequence lane below
-        dec_kernel = "zlz4::k_decompress_safe<true, %s>" % ("true" if nblocks >= 6144 else "false")
-        kc = {"cfg2": "zlz4::k_compress_fast<uint16_t>", "cfg4": hc_kernels,
-              "cfg5": "zlz4::k_compress_fast<uint32_t>", "cfg3": None}[args.workload]
+        dec_kernel = "zlz4::k_decompress_safe<%s>" % ("true, true, true" if nblocks >= 6144 else "true, false, false")
+        kc = {"cfg2": "zlz4::k_compress_fast<uint16_t, 0>", "cfg4": hc_kernels,
+              "cfg5": "zlz4::k_compress_fast<uint32_t, 2>", "cfg3": None}[args.workload]
         if decomp_only:
             dom, dom_ms = dec_kernel, td_ms
         else:
