@@ -13,6 +13,7 @@
 // (offset < matchLength, src/lz4.zig:235-241) use the periodic-extension
 // identity out[op+k] = out[op-offset + (k mod offset)].
 #include <cstdlib>
+#include <type_traits>
 
 #include "zlz4_device.hpp"
 
@@ -52,14 +53,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 // decompressed size before placing the blocks (lz4f.decompressFrame accumulates dstPos serially).
 // kLaneCopy: short matches are moved four bytes per lane (batches that fill the chip); false = 16 bytes per sequence lane
 // for every match (few blocks: the shorter latency chain)
-// (eight wavefronts per SIMD = at most 64 VGPRs: the copy phases brought the lane-copy build to 66, and the seventh of eight
-//  wavefronts cost D-text 7 % -- the decoder is bound by vector issue and lives on occupancy)
+// (the decoder is bound by vector issue and lives on occupancy: eight wavefronts per SIMD = at most 64 VGPRs.  The copy
+//  phases brought the lane-copy build to 66 and the seventh-of-eight cost D-text 7 %; it is back at 62 since the lane
+//  copy keeps two rounds of registers instead of three.)
 template <bool kWrite, bool kLaneCopy = false, bool kPhases = kLaneCopy>
-#ifdef ZLZ4_DEC_NO_WPE
 __global__ __launch_bounds__(256) void k_decompress_safe(
-#else
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decompress_safe(
-#endif
     const uint8_t *__restrict__ d_in, const uint64_t *__restrict__ d_in_off,
     const uint32_t *__restrict__ d_in_len, uint8_t *d_out, const uint64_t *__restrict__ d_out_off,
     const uint32_t *__restrict__ d_out_cap, int64_t *__restrict__ d_result, uint32_t nblocks, uint32_t min_phase_tokens) {
@@ -301,6 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 // (what is left is the next phase, or the next batch)
                 auto cap_short = [&]() {
                     if constexpr (kWrite && kLaneCopy) {
+                        if ((uint32_t)__popcll(R) <= 16u) return;    // (scalar: the usual batch has 8 tokens)
                         const bool sh = ((R >> lane) & 1ull) && ml <= short_max;
                         const uint64_t S = ballot(sh);
                         if ((uint32_t)__popcll(S) > 16u) {
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                         }
                     }
                 };
-                auto copy_side = [&]() {
+                auto copy_side = [&](auto later_phase) {
                 if (kWrite) {
                     flush_pending();                                // the previous phase's / batch's match stores
                     DSTAMP(7);
@@ -322,7 +321,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const uint32_t q = shfl(relv | (lit << 16), kl);
                     const uint32_t qlit = q >> 16;
                     const uint32_t d = lane - kl - (qlit >= 15u ? 2u : 1u);
-                    if (d < qlit && below != 0) dst[op0 + (q & 0xFFFFu) + d] = (uint8_t)b0;
+                    // (in a later phase the lanes in front of its first token belong to nobody)
+                    if (d < qlit && (!decltype(later_phase)::value || below != 0)) dst[op0 + (q & 0xFFFFu) + d] = (uint8_t)b0;
                     DSTAMP(3);
                     // matches (:244): source entirely older than this phase's first match, no overlap.  One or two
                     // 16-byte loads per sequence lane; the data is stored by flush_pending() after the next batch
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
                 };
                 cap_short();
-                copy_side();
+                copy_side(std::false_type{});
                 // ---- further phases: only the copy pass has them, only if the phase before was cut short, only while
                 //      enough tokens are left to pay for a phase (it costs about half a batch; a batch that lost its last
                 //      token or two is better off starting the next batch there), and only while the token that cut it can
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                         // of the copy side: every way into it passes this wait -- tools/check_decoder_asm.py)
                         cap_short();
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa), "+v"(pb), "+v"(pd0), "+v"(pd1), "+v"(tdummy), "+v"(X2));
-                        copy_side();
+                        copy_side(std::true_type{});
                     }
                 }
                 op += T;
