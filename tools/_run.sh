@@ -1,11 +1,7 @@
 set -e
-mkdir -p gpurun_out/r3k
-rm -f gpurun_out/r3k/ab.txt
-for rep in 1 2; do
-  ZLZ4_AMD_LIB=$PWD/zig-lz4_amd/libzlz4_amd_r02.so python tools/time_decompress.py text 65536 2>/dev/null | sed "s/^/r02 /" >> gpurun_out/r3k/ab.txt
-  export ZLZ4_AMD_LIB=$PWD/zig-lz4_amd/libzlz4_amd_tuning.so
-  python tools/time_decompress.py text 65536 2>/dev/null | sed "s/^/cur /" >> gpurun_out/r3k/ab.txt
-  ZLZ4_DECOMP_PHASE_MIN=64 python tools/time_decompress.py text 65536 2>/dev/null | sed "s/^/cur-min64 /" >> gpurun_out/r3k/ab.txt
-  ZLZ4_DECOMP_PHASES=0 python tools/time_decompress.py text 65536 2>/dev/null | sed "s/^/cur-nophase /" >> gpurun_out/r3k/ab.txt
+mkdir -p gpurun_out/r3l
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_shipped_paths.py tests/test_gpu_frame.py tests/test_gpu_large.py -m gpu -x -q -k "hc or golden or optimal or max_in_len or graph or frame or verify or mirror" > gpurun_out/r3l/parity.txt 2>&1 || { tail -30 gpurun_out/r3l/parity.txt; exit 1; }
+tail -3 gpurun_out/r3l/parity.txt
+for d in text reptext zero; do
+python bench.py --workload cfg4 --dist $d --steps 5 --warmup 2 --no-cpu 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$d L9 comp %.2f ms %.2f GiB/s'%(d['compress_ms'],d['compress_gibs_per_gpu']))"
 done
-cat gpurun_out/r3k/ab.txt
