@@ -488,9 +488,11 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 
-    bool have = false, exhausted = false, in_chain = false, in_ext = false, fresh = false;
-    bool is_true = false;                                        // this lane runs the walk that started at position 0
-    bool ext_final = false;                                      // `off` already is the candidate's full match length
+    // (lane state as 0 / 1 in VECTOR registers: as `bool` each of them is a 64-bit lane mask in two scalar registers for the
+    //  whole loop, and the scalar registers are what this kernel runs out of)
+    uint32_t have = 0, exhausted = 0, in_chain = 0, in_ext = 0, fresh = 0;
+    uint32_t is_true = 0;                                        // this lane runs the walk that started at position 0
+    uint32_t ext_final = 0;                                      // `off` already is the candidate's full match length
     uint32_t fword_next = 0;                                     // frontier word of the walk from 0, as of the previous trip
     u32x4 p16 = {0, 0, 0, 0};                                    // the 16 bytes at pos
     u32x4 aw = p16;                                              // the 16 bytes at pos + aw_off (the compare window)
