@@ -14,16 +14,19 @@
 // table state a search at position p sees is a pure function of the input:
 //     hashTable[h(p)]  at the time p is searched = prev(p) = the last q < p with h(q) == h(p)
 //     chainTable[q]                                = min(q - prev(q), 65535)        (prev = 0 if none)
-// That turns the serial insert/search loop into three data-parallel passes:
-//   K1 build_links   one wavefront per block, 32768-entry hash table in LDS, 64 positions per
-//                    step (duplicate hashes inside a step resolved with ballot groups);
-//                    writes link[q] (the chain) to HBM, coalesced.
-//   K2 search        one LANE per position: walks the chain exactly as :571-622 (+ the level-9
-//                    pattern analysis :626-678) and stores the best (len, off) per position.
-//   K3 parse_emit    one wavefront per block: the greedy walk of :1009-1032 over the stored
-//                    results, encodeSequence with its limitedOutput checks, final literals.
-// K2 does redundant work for positions inside matches, but it has 64K-way parallelism per
-// block where the reference has none.
+// That turns the serial insert/search loop into three data-parallel passes (DESIGN.md section 4.3):
+//   K1 k_hc_build_links   one block per CU, four wavefronts: insertHC for 256 positions per step as ONE LDS atomic max
+//                         with return per 64 positions (128 KiB 32-bit hash table in LDS); writes link[q] to HBM.
+//   K2s k_hc_seg_search   (levels 3-9) one 1024-lane workgroup per block, the block's links in LDS.  The greedy parse is
+//                         a walk in a functional graph (next(p) = p + len(p) or p + 1), so walks that start every 32
+//                         positions run speculatively, mark what they search, and stop where somebody else has been;
+//                         the walk from position 0 is the parse.  Only positions on some walk are searched (:571-622,
+//                         + the level-9 pattern analysis :626-678), four candidates per trip, matches stored per position.
+//   K2  k_hc_search       (levels 10-12, whose price-based parse looks results up everywhere; and blocks > 64 KiB at
+//                         every level's A/B switch) one LANE per position walks its chain.
+//   K3  k_hc_parse_emit   one wavefront per block: the greedy walk of :1009-1032 over the stored results,
+//                         encodeSequence with its limitedOutput checks, final literals; runs on a side stream beside
+//                         K1 / K2s of the next round.
 #include <cstdlib>
 #include <type_traits>
 

@@ -2,13 +2,18 @@
 //   level 2      lz4mid  compressMID      (:687-971)   dual 4-byte / 8-byte hash tables, strictly serial
 //   level 10-12  lz4opt  compressOptimal  (:1068-1391) price-based parse over the hash-chain matches
 //
-// Both parses are serial inside a block and carry far more state than a wavefront can share cheaply
-// (128 KiB of tables for lz4mid, a 4099-entry price array for lz4opt), so here the batch dimension is the
-// parallel one: ONE LANE PER BLOCK runs the serial parse exactly as the reference does, 64 blocks per
-// wavefront, state in an HBM workspace.  The expensive part of lz4opt -- the match search
-// (insertAndGetWiderMatch, :538-681) -- does not run here: as for levels 3-9 the table state a search sees is
-// a pure function of the input, so K1/K2 of zlz4_compress_hc.hip produce the best match of every position
-// with full parallelism and this parse only looks results up.
+// Both parses are serial inside a block.
+//   level 2:      `compressMID`'s tables depend on the parse (it inserts around every match it takes), a probe is two table
+//                 lookups and one 8-byte compare, and 128 KiB of tables do not fit beside a second block in LDS -- so the
+//                 batch dimension is the parallel one: ONE LANE PER BLOCK (two blocks per wavefront) runs the serial loop
+//                 with its tables in an HBM workspace (k_hc_mid_serial; DESIGN.md 4.3b says what a wavefront per block
+//                 would cost).
+//   levels 10-12: the expensive part -- the match search (insertAndGetWiderMatch, :538-681) -- does not run here: as for
+//                 levels 3-9 the table state a search sees is a pure function of the input, so K1 / K2 of
+//                 zlz4_compress_hc.hip produce the best match of every position with full parallelism and the parse only
+//                 looks results up.  The parse itself: ONE WAVEFRONT PER BLOCK for blocks <= 64 KiB
+//                 (k_hc_opt_parse_wave: price records in LDS, the lanes take the match lengths of a position), one lane
+//                 per block with the records in HBM for larger blocks (k_hc_opt_parse).
 //
 // NOTE (reference behaviour, reproduced on purpose): the "match is good enough -> encode immediately" branch
 // of compressOptimal (:1207-1256) walks opt[] forward WITHOUT the reverse traversal of the normal path
