@@ -246,7 +246,11 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                     const uint32_t d2 = first_diff16_sel(f2, c2);
                     mlo += d2 == 16u ? 16u + first_diff16_sel(f3, c3) : d2;
                 }
-                const bool single = grp == lane_bit;
+                // a lane whose hash no EARLIER lane of the window shares reads the pre-window value whatever the parse does --
+                // the only lane of its hash, or the first of a duplicate group (round 3: the first of a group used to take
+                // an exact step like the others, which found no in-window candidate and fell back to the same registers;
+                // 0.55 of the 0.72 exact steps per window on text were on duplicate-hash lanes, half of them first ones)
+                const bool single = (grp & lanes_below) == 0;
                 const bool oldfast = vo && mlo < 44u;         // result against the pre-window value is complete in registers
                 const uint64_t wrmask = ballot(wr);
                 const uint64_t cfast = ballot(oldfast);                                       // usable if no in-window put precedes
