@@ -1,5 +1,6 @@
 set -e
-mkdir -p gpurun_out/r3q
-export ZLZ4_AMD_LIB=$PWD/zig-lz4_amd/libzlz4_amd_tuning.so ZLZ4_DECOMP_SHORT=32
-timeout -k 10 1100 python tools/fuzz_parity.py --check tests/_fuzz_cache/r3a.npz > gpurun_out/r3q/fuzz_a_phases.txt 2>&1 || { tail -20 gpurun_out/r3q/fuzz_a_phases.txt; exit 1; }
-tail -2 gpurun_out/r3q/fuzz_a_phases.txt
+mkdir -p gpurun_out/r3r
+ZLZ4_AMD_LIB=$PWD/zig-lz4_amd/libzlz4_amd_stamps.so python tools/stamp_profile.py text 65536 2>&1 | grep -v amdgpu > gpurun_out/r3r/st.txt
+echo "=== no flush stores (timing only, output wrong)" >> gpurun_out/r3r/st.txt
+ZLZ4_AMD_LIB=$PWD/zig-lz4_amd/libzlz4_amd_stamps_ns.so python tools/stamp_profile.py text 65536 2>&1 | grep -v amdgpu >> gpurun_out/r3r/st.txt
+cat gpurun_out/r3r/st.txt
