@@ -831,9 +831,13 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
         const uint32_t mflimit = n - kMfLimit;                   // :988
         uint32_t ip = 0, anchor = 0, op = 0;
         bool failed = false;
-        // 64-position window of search results held in registers
+        // 64-position window of search results held in registers -- and the window's input bytes with it: a sequence's
+        // literals are stored straight from them (a byte per lane), so the loop has no load that a store waits for (round 3;
+        // copy_bytes' load -> store per sequence made this kernel a chain of ~1 900-cycle steps).  The window starts at the
+        // anchor whenever the pending literal run is shorter than 64 bytes, so its literals are inside.
         uint32_t wbase = 0;
         R w = (lane <= mflimit) ? res[lane] : (R)0;
+        uint32_t sb = lane < n ? src[lane] : 0u;
         // lanes of the window whose position holds a match; the loop steps over the others one by one (:1013-1016), i.e.
         // it goes to the first such lane at or after ip
         auto is_match = [](R r) {
@@ -843,8 +847,9 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
         uint64_t wmatch = ballot(is_match(w));
         while (ip <= mflimit) {                                  // :1009
             if (ip - wbase >= 64u) {
-                wbase = ip;
-                w = (ip + lane <= mflimit) ? res[ip + lane] : (R)0;
+                wbase = ip - anchor < 64u ? anchor : ip;
+                w = (wbase + lane <= mflimit) ? res[wbase + lane] : (R)0;
+                sb = wbase + lane < n ? src[wbase + lane] : 0u;
                 wmatch = ballot(is_match(w));
             }
             const uint64_t ahead = wmatch >> (ip - wbase);
@@ -868,7 +873,12 @@ __global__ __launch_bounds__(256) void k_hc_parse_emit(const uint8_t *__restrict
             if (lane == 0)
                 dst[op] = (uint8_t)(((lit >= 15u ? 15u : lit) << 4) | (ml_code >= 15u ? 15u : ml_code));
             if (lit >= 15u) write_ext_len(dst + op + 1u, lit, lane);
-            copy_bytes(dst + op + 1u + nle, src + anchor, lit, lane);   // :346
+            if (anchor >= wbase) {                               // :346 (ip - wbase < 64 here: the literals are window bytes)
+                const uint32_t a0 = anchor - wbase;
+                if (lane >= a0 && lane < a0 + lit) dst[op + 1u + nle + (lane - a0)] = (uint8_t)sb;
+            } else {
+                copy_bytes(dst + op + 1u + nle, src + anchor, lit, lane);
+            }
             if (lane < 2u) dst[op2 - 2u + lane] = (uint8_t)(off >> (8u * lane));   // :350
             if (ml_code >= 15u) write_ext_len(dst + op2, ml_code, lane);           // :361-376 (510-steps == 255-run)
             op = op2 + nme;
