@@ -429,7 +429,7 @@ __device__ __forceinline__ uint32_t hc_coop_count(const uint8_t *__restrict__ sr
 //               in the workspace (zeroed by the launcher).  Here the walk also meets the two tests that cannot fire in
 //               a 64 KiB block: candidates further than 65535 bytes end the walk (:573), candidates below
 //               lowestMatchIndex are counted but not compared (:579).
-template <int kCands, bool kLds>   // kCands = candidates of a chain examined per loop trip (1, 2 or 4)
+template <int kCands, bool kLds>   // kCands = candidates of a chain examined per loop trip (1, 2, 4 or 8; 4 ships)
 __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restrict__ d_in,
                                                          const uint64_t *__restrict__ d_in_off,
                                                          const uint32_t *__restrict__ d_in_len,
@@ -675,77 +675,77 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 // (bytes 0..15 while best_len < 16): a mismatch there settles it in one load, whatever the candidate's
                 // real length -- at level 9 a frequent 4-gram has 256 candidates that match 20-40 bytes each.
                 const uint32_t w = best_len >= 16 ? (uint32_t)best_len - 15u : 0u;
-                const uint32_t c0 = m, l0 = delta_of(c0, lk[c0]);                 // l_k = distance to the next candidate
-                uint32_t c1 = 0, l1 = 0, c2 = 0, l2 = 0, c3 = 0, l3 = 0;
-                u32x4 b1 = {0, 0, 0, 0}, b2 = b1, b3 = b1;
-                if constexpr (kCands >= 2) {
-                    const bool k1 = !(l0 == 0 || l0 > c0) && c0 - l0 > 0;
-                    c1 = k1 ? c0 - l0 : 0; l1 = delta_of(c1, lk[c1]);
-                    if constexpr (kCands >= 4) {
-                        const bool k2 = k1 && !(l1 == 0 || l1 > c1) && c1 - l1 > 0;
-                        c2 = k2 ? c1 - l1 : 0; l2 = delta_of(c2, lk[c2]);
-                        const bool k3 = k2 && !(l2 == 0 || l2 > c2) && c2 - l2 > 0;
-                        c3 = k3 ? c2 - l2 : 0; l3 = delta_of(c3, lk[c3]);
+                uint32_t c[kCands], l[kCands];                   // candidates of this trip, l[k] = distance to the next one
+                c[0] = m; l[0] = delta_of(c[0], lk[c[0]]);
+                {
+                    bool more_k = true;
+#pragma unroll
+                    for (int k = 1; k < kCands; k++) {
+                        more_k = more_k && !(l[k - 1] == 0 || l[k - 1] > c[k - 1]) && c[k - 1] - l[k - 1] > 0;
+                        c[k] = more_k ? c[k - 1] - l[k - 1] : 0; l[k] = delta_of(c[k], lk[c[k]]);
                     }
                 }
                 if (fresh) { p16 = ld128(src + pos); aw_off = 0; fresh = false; }
                 if (aw_off != w) { aw = ld128(src + pos + w); aw_off = w; }      // pos + w + 16 = pos + best_len + 1 <= n - 4
                 const u32x4 awin = w == 0u ? p16 : aw;           // (a select after the loads: no wait on p16 alone)
-                const u32x4 b0 = ld128(src + c0 + w);
-                if constexpr (kCands >= 2) b1 = ld128(src + c1 + w);
-                if constexpr (kCands >= 4) { b2 = ld128(src + c2 + w); b3 = ld128(src + c3 + w); }
                 // (a candidate slot that the walk does not reach holds position 0: a harmless load, never looked at)
-                const uint32_t fd0 = first_diff16_sel(awin, b0);
-                uint32_t fd1 = 0, fd2 = 0, fd3 = 0;
-                if constexpr (kCands >= 2) fd1 = first_diff16_sel(awin, b1);
-                if constexpr (kCands >= 4) { fd2 = first_diff16_sel(awin, b2); fd3 = first_diff16_sel(awin, b3); }
+                u32x4 bk[kCands];
+#pragma unroll
+                for (int k = 0; k < kCands; k++) bk[k] = ld128(src + c[k] + w);
+                uint32_t fd[kCands];
+#pragma unroll
+                for (int k = 0; k < kCands; k++) fd[k] = first_diff16_sel(awin, bk[k]);
                 // Fast path: every candidate the walk reaches in this trip is rejected by the window test (the usual
                 // case on a long chain).  Then nothing but the attempt counter and the walk position change, exactly as
-                // :577 / :619-621 would leave them.  att_k = candidate k is attempted (:571, :573), rej_k = it cannot
-                // beat best_len (or lies below lowestMatchIndex, :579), end_k = the chain ends behind it (:620).
-                auto rejected = [&](uint32_t c, uint32_t fd) {
-                    const uint32_t cl = fd < avail ? fd : avail;             // lz4Count stops at iHighLimit
-                    const bool r = w != 0u ? fd != 16u : (fd < kMinMatch) | ((fd < 16u) & ((int32_t)cl <= best_len));
-                    return kLds ? r : (r | (c < lowest));
+                // :577 / :619-621 would leave them.  att[k] = candidate k is attempted (:571, :573), rejected = it cannot
+                // beat best_len (or lies below lowestMatchIndex, :579), end[k] = the chain ends behind it (:620).
+                auto rejected = [&](uint32_t cc, uint32_t fdd) {
+                    const uint32_t cl = fdd < avail ? fdd : avail;           // lz4Count stops at iHighLimit
+                    const bool r = w != 0u ? fdd != 16u : (fdd < kMinMatch) | ((fdd < 16u) & ((int32_t)cl <= best_len));
+                    return kLds ? r : (r | (cc < lowest));
                 };
-                auto near_enough = [&](uint32_t c) { return kLds || pos - c <= kMaxDist; };
-                const bool end0 = (l0 == 0) | (l0 > c0);
-                bool att1 = false, att2 = false, att3 = false, end1 = true, end2 = true, end3 = true;
-                if constexpr (kCands >= 2) { att1 = !end0 & (c0 - l0 > 0) & (nb > 1) & near_enough(c1); end1 = (l1 == 0) | (l1 > c1); }
-                if constexpr (kCands >= 4) {
-                    att2 = att1 & !end1 & (c1 - l1 > 0) & (nb > 2) & near_enough(c2); end2 = (l2 == 0) | (l2 > c2);
-                    att3 = att2 & !end2 & (c2 - l2 > 0) & (nb > 3) & near_enough(c3); end3 = (l3 == 0) | (l3 > c3);
+                auto near_enough = [&](uint32_t cc) { return kLds || pos - cc <= kMaxDist; };
+                // (0 / 1 in vector registers, like the lane state: as `bool` these are two scalar registers each)
+                uint32_t att[kCands], end[kCands];
+                att[0] = 1u; end[0] = (uint32_t)((l[0] == 0) | (l[0] > c[0]));
+                uint32_t all_rej = (uint32_t)rejected(c[0], fd[0]);
+#pragma unroll
+                for (int k = 1; k < kCands; k++) {
+                    att[k] = att[k - 1] & (end[k - 1] ^ 1u) & (uint32_t)(c[k - 1] - l[k - 1] > 0) & (uint32_t)(nb > k) & (uint32_t)near_enough(c[k]);
+                    end[k] = (uint32_t)((l[k] == 0) | (l[k] > c[k]));
+                    all_rej = all_rej & ((att[k] ^ 1u) | (uint32_t)rejected(c[k], fd[k]));
                 }
-                const bool all_rej = rejected(c0, fd0) & (!att1 | rejected(c1, fd1)) & (!att2 | rejected(c2, fd2)) &
-                                     (!att3 | rejected(c3, fd3));
                 if (all_rej) {
-                    const uint32_t cl = att3 ? c3 : att2 ? c2 : att1 ? c1 : c0;          // the last candidate attempted
-                    const uint32_t ll = att3 ? l3 : att2 ? l2 : att1 ? l1 : l0;
-                    const bool el = att3 ? end3 : att2 ? end2 : att1 ? end1 : end0;
-                    nb -= 1 + (int32_t)att1 + (int32_t)att2 + (int32_t)att3;              // :577
+                    uint32_t cl = c[0], ll = l[0];               // the last candidate attempted
+                    uint32_t el = end[0];
+                    int32_t natt = 1;
+#pragma unroll
+                    for (int k = 1; k < kCands; k++) {
+                        cl = att[k] ? c[k] : cl; ll = att[k] ? l[k] : ll; el = att[k] ? end[k] : el;
+                        natt += (int32_t)att[k];
+                    }
+                    nb -= natt;                                                           // :577
                     m = el ? cl : cl - ll;                                                // :620-621
                     done = !((bool)((int)!el & (int)(nb > 0) & (int)(m > 0) & (int)near_enough(m)));   // :571, :573
                 } else {
                 // (after a candidate that raised best_len the rest of the trip is dropped: their window is stale)
-                #define ZLZ4_HC_CAND(C, L, FD)                                                                  \
-                    if (!done && !in_ext && !changed) {                                                         \
-                        const uint32_t fd = (FD);                                                               \
-                        if (!kLds && (C) < lowest) { if (!complete((C), (L), 0u)) done = true; }    /* :579 */  \
-                        else if (w != 0) {                                                                      \
-                            if (fd == 16u) { m = (C); off = 0; in_ext = true; }          /* count it from byte 0 */ \
-                            else if (!complete((C), (L), 0u)) done = true;                                      \
-                        } else {                                                                                \
-                            uint32_t total = fd;                                                                \
-                            bool more = total == 16u && total < avail;                                          \
-                            if (more && pos + 32u > n) { total += lz4_count(src, pos + 16u, (C) + 16u, limit); more = false; } \
-                            if (more) { m = (C); off = 16u; in_ext = true; }                                    \
-                            else if (!complete((C), (L), total)) done = true;                                   \
-                        }                                                                                       \
+#pragma unroll
+                for (int k = 0; k < kCands; k++) {
+                    if (!done && !in_ext && !changed) {
+                        const uint32_t fdk = fd[k];
+                        if (!kLds && c[k] < lowest) { if (!complete(c[k], l[k], 0u)) done = true; }    /* :579 */
+                        else if (w != 0) {
+                            if (fdk == 16u) { m = c[k]; off = 0; in_ext = true; }          /* count it from byte 0 */
+                            else if (!complete(c[k], l[k], 0u)) done = true;
+                        } else {
+                            uint32_t total = fdk;
+                            bool more = total == 16u && total < avail;
+                            if (more && pos + 32u > n) { total += lz4_count(src, pos + 16u, c[k] + 16u, limit); more = false; }
+                            if (more) { m = c[k]; off = 16u; in_ext = true; }
+                            else if (!complete(c[k], l[k], total)) done = true;
+                        }
                     }
-                ZLZ4_HC_CAND(c0, l0, fd0)
-                if constexpr (kCands >= 2) { ZLZ4_HC_CAND(c1, l1, fd1) }
-                if constexpr (kCands >= 4) { ZLZ4_HC_CAND(c2, l2, fd2) ZLZ4_HC_CAND(c3, l3, fd3) }
-                #undef ZLZ4_HC_CAND
+                }
                 }
             } else {
                 // the candidate at m matched `off` bytes so far: the next 16
@@ -991,7 +991,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
         const uint32_t lds = kLds ? lk_bytes + ((np_max + 31u) / 32u + 3u) * 4u : 16u;
         static const int cands = [] { const char *e = zlz4_tune_env("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
-        auto kern = cands == 4 ? &k_hc_seg_search<4, kLds> : cands == 2 ? &k_hc_seg_search<2, kLds> : &k_hc_seg_search<1, kLds>;
+        auto kern = cands == 8 ? &k_hc_seg_search<8, kLds> : cands == 4 ? &k_hc_seg_search<4, kLds> : cands == 2 ? &k_hc_seg_search<2, kLds> : &k_hc_seg_search<1, kLds>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const uint64_t bm_stride = (stride + 31u) / 32u + 1u;                // bitmap words per block (HBM links only)
         uint32_t *d_bitmap = static_cast<uint32_t *>(d_opt);                 // (the area of the price-based parse is idle here)
