@@ -58,3 +58,22 @@ def test_shard_ranges_cover_everything():
             r = [shard.shard_range(nb, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == nb and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_bench_launcher_starts_its_own_ranks_and_reports_failures():
+    """`python bench.py --gpus 2` without a launcher starts two child ranks itself (RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would) and never touches the GPU in the parent.  On this box the children cannot find a GPU:
+    the parent must come back with a non-zero exit code, name the failed rank and print no JSON line."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--blocks", "64"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    import torch
+    if torch.cuda.is_available():          # (on a GPU box this is a real two-rank run on one device: not what is tested here)
+        return
+    assert r.returncode != 0
+    assert "exited with" in r.stderr and "rank" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
