@@ -211,6 +211,21 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 const bool old_ok = wr && old > 0 && (old + kMaxDist >= pos) && (kTag == 0 || told == tg);
                 u32x4 cold = {0, 0, 0, 0};
                 if (old_ok) cold = ld128(src + old);
+                // the second compare level (bytes 16..47, below) is a round trip of its own behind the first -- unless it is
+                // asked for now: a lane whose candidate and the candidate twelve lanes on are twelve bytes apart sits at the
+                // start of >= 16 matching bytes almost certainly, and fetches its 32 more bytes with the gather (a wrong
+                // guess costs two loads; a lane that was not guessed fetches them when it knows, as before)
+                // (blocks > 64 KiB only: few large blocks leave the chip to one wavefront per SIMD, where the round trip is
+                //  what counts -- 1024 x 4 MiB 121.5 -> 118.9 ms; with 20 wavefronts per CU the extra requests cost more
+                //  than the round trip, configs[1] 41.3 -> 41.6 ms, D-reptext 58.9 -> 60.3 ms)
+                constexpr bool kGuess2 = sizeof(T) == 4;
+                const uint32_t old12 = kGuess2 ? shfl(old, (lane + 12u) & 63u) : 0u;
+                const bool pred2 = kGuess2 && old_ok && lane < 52u && old12 == old + 12u;
+                u32x4 f2 = {0, 0, 0, 0}, c2 = f2, f3 = f2, c3 = f2;
+                if (pred2) {
+                    f2 = ld128(src + pos + 16u); c2 = ld128(src + old + 16u);
+                    f3 = ld128(src + pos + 32u); c3 = ld128(src + old + 32u);
+                }
                 STAMP(3);
                 if (wr) table[h] = (T)mine;                             // :350 (speculative)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -240,9 +255,12 @@ __global__ __launch_bounds__(256) void k_compress_fast(
                 }
                 // second level: the few lanes whose 16 bytes all match compare 16 more (matches of 16..31 bytes are a
                 // fifth of all sequences on text; without this each of them costs an exact step and its own emission)
-                if (vo && mlo == 12u) {                       // (all four loads in one round trip)
-                    const u32x4 f2 = ld128(src + pos + 16u), c2 = ld128(src + old + 16u);
-                    const u32x4 f3 = ld128(src + pos + 32u), c3 = ld128(src + old + 32u);
+                const bool need2 = vo && mlo == 12u;
+                if (need2 && !pred2) {                        // (all four loads in one round trip)
+                    f2 = ld128(src + pos + 16u); c2 = ld128(src + old + 16u);
+                    f3 = ld128(src + pos + 32u); c3 = ld128(src + old + 32u);
+                }
+                if (need2) {
                     const uint32_t d2 = first_diff16_sel(f2, c2);
                     mlo += d2 == 16u ? 16u + first_diff16_sel(f3, c3) : d2;
                 }
