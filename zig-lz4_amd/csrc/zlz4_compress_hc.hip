@@ -212,7 +212,18 @@ __device__ __forceinline__ uint32_t lz4_count(const uint8_t *src, uint32_t a, ui
 // countPattern (:170-199) for a pattern that passed isRepetitivePattern (all four bytes equal)
 __device__ __forceinline__ uint32_t count_pattern(const uint8_t *src, uint32_t a, uint32_t end, uint32_t pattern) {
     uint32_t c = 0;
-    while (a + 16u <= end) {                            // (16 bytes per round trip: this loop is one lane's serial chain)
+    // (this loop is one lane's serial chain: 64 bytes per round trip while the run lasts -- a block of one repeated byte
+    //  counts 2 x 64 KiB here)
+    while (a + 64u <= end) {
+        const u32x4 v0 = ld128(src + a), v1 = ld128(src + a + 16u), v2 = ld128(src + a + 32u), v3 = ld128(src + a + 48u);
+        const uint32_t d = (v0.x ^ pattern) | (v0.y ^ pattern) | (v0.z ^ pattern) | (v0.w ^ pattern) |
+                           (v1.x ^ pattern) | (v1.y ^ pattern) | (v1.z ^ pattern) | (v1.w ^ pattern) |
+                           (v2.x ^ pattern) | (v2.y ^ pattern) | (v2.z ^ pattern) | (v2.w ^ pattern) |
+                           (v3.x ^ pattern) | (v3.y ^ pattern) | (v3.z ^ pattern) | (v3.w ^ pattern);
+        if (d) break;                                   // the 16-byte loop below finds the byte
+        a += 64; c += 64;
+    }
+    while (a + 16u <= end) {
         const u32x4 v = ld128(src + a);
         const uint32_t x0 = v.x ^ pattern, x1 = v.y ^ pattern, x2 = v.z ^ pattern, x3 = v.w ^ pattern;
         if (x0 | x1 | x2 | x3) {
@@ -236,6 +247,14 @@ __device__ __forceinline__ uint32_t count_pattern(const uint8_t *src, uint32_t a
 __device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, uint32_t a, uint32_t pattern) {
     uint32_t c = 0;
     const uint8_t pb = (uint8_t)pattern;
+    while (a >= 64u) {                                  // (64 bytes per round trip, as in count_pattern)
+        const u32x4 v0 = ld128(src + a - 16u), v1 = ld128(src + a - 32u), v2 = ld128(src + a - 48u), v3 = ld128(src + a - 64u);
+        if ((v0.x ^ pattern) | (v0.y ^ pattern) | (v0.z ^ pattern) | (v0.w ^ pattern) |
+            (v1.x ^ pattern) | (v1.y ^ pattern) | (v1.z ^ pattern) | (v1.w ^ pattern) |
+            (v2.x ^ pattern) | (v2.y ^ pattern) | (v2.z ^ pattern) | (v2.w ^ pattern) |
+            (v3.x ^ pattern) | (v3.y ^ pattern) | (v3.z ^ pattern) | (v3.w ^ pattern)) break;
+        a -= 64; c += 64;
+    }
     while (a >= 16u) {
         const u32x4 v = ld128(src + a - 16u);
         if ((v.x ^ pattern) | (v.y ^ pattern) | (v.z ^ pattern) | (v.w ^ pattern)) break;
