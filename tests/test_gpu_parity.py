@@ -333,3 +333,21 @@ def test_batch_calls_capture_into_a_hip_graph(zl, oracle, gpu):
         b = bytes(host[i])
         assert bytes(cf[i * slot: i * slot + int(r_f[i])]) == oracle.compress_default(b), i
         assert bytes(ch[i * slot: i * slot + int(r_h[i])]) == oracle.compress_hc(b, 9), i
+
+
+def test_decompress_long_overlapping_matches_of_every_period_class(zl, oracle, gpu):
+    """Matches that overlap their own output (offset < match length, src/lz4.zig:235-241) with periods below 16, of
+    16..63, 64..1023 (copied by doubling: offset, 2 x offset, 4 x offset ... bytes at a time) and >= 1024 bytes, at lengths
+    that are and are not multiples of 16 or of the period: random period content repeated, compressed by the oracle
+    (fast and HC give different offset / length splits), decoded on the device."""
+    rng = np.random.default_rng(99)
+    items = []
+    for period in (1, 2, 3, 7, 15, 16, 17, 31, 63, 64, 65, 100, 255, 256, 257, 500, 1000, 1023, 1024, 1025, 3000):
+        for total in (period * 3 + 5, 4096 + period, 65536, 30011):
+            pat = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+            head = rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8).tobytes()
+            items.append((head + pat * (total // period + 2))[:max(total, 13)])
+    comp = [oracle.compress_default(b) for b in items] + [oracle.compress_hc(b, 9) for b in items]
+    caps = [len(b) for b in items] * 2
+    got = gh.decompress(zl, comp, caps, gpu)
+    _cmp(["periodic%d" % i for i in range(len(comp))], got, items + items)

@@ -513,7 +513,17 @@ __global__ __launch_bounds__(256) void k_decompress_safe(
                 // disjoint, or far enough apart that 1 KiB chunks in address order are exact (:244 / :238-240)
                 copy_bytes(o, m, ml, lane);
             } else if (offset >= 64u) {
-                for (uint32_t k = lane; k < ml; k += 64u) o[k] = m[k];
+                // overlap with a period of 64..1023 bytes (:235-241 copies it byte by byte): the output is the period
+                // repeated, so what has been produced so far can be copied again as a whole -- offset bytes, then 2 x, 4 x ...
+                // -- every copy disjoint from its source (round 3; one byte per lane and step took 1024 dependent steps for a
+                // 64 KiB match: D-ramp, period 256)
+                uint32_t made = 0;                                  // o[0, made) is done; m[0, made + offset) holds the pattern
+                while (made < ml) {
+                    const uint32_t have = made + offset, left = ml - made;
+                    const uint32_t n1 = have < left ? have : left;
+                    copy_bytes(o + made, m, n1, lane);
+                    made += n1;
+                }
             } else {
                 // RLE-style overlap: every output byte is m[k mod offset]; with a chunk that is a
                 // multiple of `offset` each lane's value is loop-invariant.
