@@ -516,6 +516,17 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     uint32_t is_true = 0;                                        // this lane runs the walk that started at position 0
     uint32_t ext_final = 0;                                      // `off` already is the candidate's full match length
     uint32_t fword_next = 0;                                     // frontier word of the walk from 0, as of the previous trip
+    // Hand-over of the true walk (blocks <= 64 KiB).  When the walk from 0 arrives at a position X somebody else has marked,
+    // the parse goes on in that walk -- but only the true walk publishes the frontier that retires the others and keeps
+    // them from counting huge matches, so without a hand-over a block whose first long match sits where a speculative walk
+    // got first (any input with a period: the ramp of the reference's tests) had every walk count its own 64 KiB match
+    // (level 9 on D-ramp: 199 ms per GiB).  The frontier word carries the offer: X | bit 30 = "the parse continues in the
+    // walk that is searching X".  The owner of X takes it if it is still searching X (a walk that waits for the frontier
+    // before a long count always is) simply by becoming the true walk -- its own frontier store clears the bit; if nobody
+    // has after four trips, the old rule applies (the walk from 0 is declared over, bit 31).
+    constexpr uint32_t kOffer = 1u << 30;
+    uint32_t hand_wait = 0, hand_pos = 0;
+    uint32_t trips = 0;          // safety net: after 2^18 trips nobody waits for a frontier any more (a block takes 10^2..10^4)
     u32x4 p16 = {0, 0, 0, 0};                                    // the 16 bytes at pos
     u32x4 aw = p16;                                              // the 16 bytes at pos + aw_off (the compare window)
     uint32_t aw_off = 0;
@@ -550,10 +561,26 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         // (read one trip ahead: both the frontier and the flag only ever grow, a stale value is merely less helpful)
         const uint32_t fword = fword_next;
         fword_next = __hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t frontier = fword & 0x7FFFFFFFu;           // (bit 31: the walk from 0 is over)
+        const uint32_t frontier = fword & (kLds ? 0x3FFFFFFFu : 0x7FFFFFFFu);   // (bit 31: the walk from 0 is over; bit 30: offer)
+        trips += 1;
+        if constexpr (kLds) {
+            if (rfl(fword) & kOffer) {                           // (uniform, rare) the parse continues in my walk?
+                if (have && in_chain && !is_true && pos == frontier) is_true = 1;
+            }
+            if (ballot(hand_wait != 0u)) {                       // (uniform, rare) my offer: settled?
+                if (hand_wait != 0u && --hand_wait == 0u) {
+                    // nobody took it: the walk from 0 is over (compare-and-swap: a taker's frontier store may have come since)
+                    uint32_t expect = hand_pos | kOffer;
+                    (void)__hip_atomic_compare_exchange_strong(next_seg + 1, &expect, hand_pos | 0x80000000u, __ATOMIC_RELAXED,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
         if (have && !is_true && pos < frontier) { have = false; in_chain = false; in_ext = false; ext_final = false; }
         if (have && is_true) __hip_atomic_store(next_seg + 1, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!ballot(have) && !ballot(!exhausted)) break;
+        // (a lane that has offered the hand-over keeps its wavefront in the loop until the offer is settled: walks that wait
+        //  for the frontier wait for that)
+        if (!ballot((have | (exhausted ^ 1u) | hand_wait) != 0u)) break;
         HSTAMP(t_assign, t0);
 #ifdef ZLZ4_STAMPS
         st_trips += 1; st_walks += __popcll(want); st_fetch += __popcll(ballot(have && !in_chain));
@@ -588,7 +615,14 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 if (k == 4u) continue;
                 const uint32_t l = k == 0u ? l0 : k == 1u ? l1 : k == 2u ? l2 : l3;
                 if (mark(pos)) {                                 // somebody else's walk continues from here
-                    if (is_true) __hip_atomic_fetch_or(next_seg + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (is_true) {
+                        if constexpr (kLds) {                    // ... and with it the parse: offer the hand-over
+                            __hip_atomic_store(next_seg + 1, pos | kOffer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            hand_wait = 4; hand_pos = pos;
+                        } else {
+                            __hip_atomic_fetch_or(next_seg + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
                     have = false;
                     break;
                 }
@@ -652,7 +686,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         // long count is done by the whole wavefront, 1 KiB per step, lowest lane first.
         bool parked = false;
         if (const uint64_t wantm = ballot(have && in_chain && in_ext && !ext_final && off >= 64u)) {
-            const bool walk0_over = (fword >> 31) != 0u;
+            const bool walk0_over = (fword >> 31) != 0u || trips > (1u << 18);
             const bool want = (wantm >> lane) & 1ull;
             parked = want && !is_true && !walk0_over;
             uint64_t longm = wantm & ~ballot(parked);
@@ -661,7 +695,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 longm &= longm - 1ull;
                 const uint32_t P = rdlane(pos, L);
                 const bool walk0 = rdlane((uint32_t)is_true, L) != 0;
-                if (!walk0 && P < (__hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x7FFFFFFFu)) {
+                if (!walk0 && P < (__hip_atomic_load(next_seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (kLds ? 0x3FFFFFFFu : 0x7FFFFFFFu))) {
                     if (lane == L) { have = false; in_chain = false; in_ext = false; }
                     continue;
                 }
