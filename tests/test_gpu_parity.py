@@ -351,3 +351,28 @@ def test_decompress_long_overlapping_matches_of_every_period_class(zl, oracle, g
     caps = [len(b) for b in items] * 2
     got = gh.decompress(zl, comp, caps, gpu)
     _cmp(["periodic%d" % i for i in range(len(comp))], got, items + items)
+
+
+@pytest.mark.parametrize("level", [9, 4])
+def test_compress_hc_periodic_inputs(zl, oracle, gpu, level):
+    """Blocks with a period (random content repeated every 1 .. 40000 bytes, some with noise in the middle or two periods
+    in a row): every start point's first match is the same long run, which the search kernel counts once and shares
+    between its walks (counted runs, k_hc_seg_search in zlz4_compress_hc.hip).  Bytes vs the oracle
+    (insertAndFindBestMatch / lz4Count, src/lz4hc.zig:540-640, :234-264)."""
+    rng = np.random.default_rng(4242 + level)
+    items = []
+    for period in (1, 2, 3, 5, 16, 40, 63, 64, 100, 255, 256, 257, 1000, 1024, 4096, 5000, 40000):
+        for total in (65536, 30011, period * 2 + 70):
+            pat = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+            b = bytearray((pat * (total // period + 2))[:max(total, 13)])
+            items.append(bytes(b))
+            if total > 20000:
+                for _ in range(3):                                # a few damaged bytes: runs that end early
+                    b[int(rng.integers(0, len(b)))] ^= 0x55
+                items.append(bytes(b))
+                pat2 = rng.integers(0, 256, max(1, period // 2 + 1), dtype=np.uint8).tobytes()
+                half = len(b) // 2
+                items.append(bytes(b[:half]) + (pat2 * (half // len(pat2) + 2))[:len(b) - half])   # two periods in a row
+    got = gh.compress_hc(zl, items, gpu, level)
+    want = [oracle.compress_hc(b, level) for b in items]
+    _cmp(["periodic%d" % i for i in range(len(items))], got, want)

@@ -33,9 +33,9 @@
 #include "zlz4_device.hpp"
 
 #ifdef ZLZ4_STAMPS
-__device__ unsigned long long g_zlz4_hstamps[8];
+__device__ unsigned long long g_zlz4_hstamps[16];
 extern "C" int zlz4_debug_read_hstamps(unsigned long long *out4) {
-    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_zlz4_hstamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -7;
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_zlz4_hstamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -7;
 }
 #endif
 
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
 // next 16 bytes of a candidate that matched so far.
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
 // Wave-cooperative lz4Count (:234-264) for one long match: bytes equal at a + k / b + k, k >= from, while a + k < limit;
 // 16 bytes per lane and step (1 KiB per step).  All 64 lanes must call it with the same arguments.
@@ -435,6 +436,58 @@ __device__ __forceinline__ uint32_t hc_coop_count(const uint8_t *__restrict__ sr
             else while (d < cmp && src[pa + d] == src[pb + d]) d++;
         }
         const uint64_t stop = ballot(d < 16u);            // mismatch or limit inside this lane's chunk
+        if (stop) {
+            const uint32_t sl = first_lane(stop);
+            return k + sl * 16u + rdlane(d, sl);
+        }
+        k += 1024u;
+    }
+}
+
+// Wave-cooperative countPattern (:170-199) / reverseCountPattern (:202-222) for a four-equal-bytes pattern, 1 KiB per step
+// (count_pattern / reverse_count_pattern above are one lane's serial chain: a block of one repeated byte is 2 x 64 KiB of
+// it, during which the 15 other wavefronts of the block wait for that lane -- level 9 on D-zero, round 3).  Wave-uniform
+// arguments.
+__device__ __forceinline__ uint32_t hc_coop_count_pattern(const uint8_t *__restrict__ src, uint32_t a, uint32_t end, uint32_t pattern,
+                                                          uint32_t n, uint32_t lane) {
+    const u32x4 pat4 = {pattern, pattern, pattern, pattern};
+    const uint8_t pb = (uint8_t)pattern;
+    uint32_t k = 0;
+    for (;;) {
+        const uint32_t pa = a + k + lane * 16u;
+        uint32_t cmp = 0, d = 0;
+        if (pa < end) cmp = end - pa < 16u ? end - pa : 16u;
+        if (cmp) {
+            if (pa + 16u <= n) { d = first_diff16_sel(ld128(src + pa), pat4); d = d < cmp ? d : cmp; }
+            else while (d < cmp && src[pa + d] == pb) d++;
+        }
+        const uint64_t stop = ballot(d < 16u);
+        if (stop) {
+            const uint32_t sl = first_lane(stop);
+            return k + sl * 16u + rdlane(d, sl);
+        }
+        k += 1024u;
+    }
+}
+__device__ __forceinline__ uint32_t hc_coop_reverse_count_pattern(const uint8_t *__restrict__ src, uint32_t a, uint32_t pattern, uint32_t lane) {
+    const uint8_t pb = (uint8_t)pattern;
+    uint32_t k = 0;
+    for (;;) {
+        const uint32_t top = a - k;                              // bytes [0, top) are left; this lane: the 16 below top - lane * 16
+        uint32_t d = 0;                                          // bytes equal to the pattern byte, counted downwards
+        if (top >= (lane + 1u) * 16u) {
+            const u32x4 v = ld128(src + top - (lane + 1u) * 16u);
+            const uint32_t x3 = v.w ^ pattern, x2 = v.z ^ pattern, x1 = v.y ^ pattern, x0 = v.x ^ pattern;
+            if (x3) d = (uint32_t)__builtin_clz(x3) >> 3;
+            else if (x2) d = 4u + ((uint32_t)__builtin_clz(x2) >> 3);
+            else if (x1) d = 8u + ((uint32_t)__builtin_clz(x1) >> 3);
+            else if (x0) d = 12u + ((uint32_t)__builtin_clz(x0) >> 3);
+            else d = 16u;
+        } else if (top > lane * 16u) {
+            uint32_t q = top - lane * 16u;                       // fewer than 16 bytes left: position 0 ends the count
+            while (q > 0 && src[q - 1u] == pb) { q--; d++; }
+        }
+        const uint64_t stop = ballot(d < 16u);
         if (stop) {
             const uint32_t sl = first_lane(stop);
             return k + sl * 16u + rdlane(d, sl);
@@ -473,9 +526,17 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     lds_u32 *next_seg;                                           // start-point counter
     [[maybe_unused]] lds_u32 *bm_l = nullptr;                    // visited bitmap, one bit per position
     [[maybe_unused]] uint32_t *bm_g = nullptr;
+    // Counted runs (blocks <= 64 KiB): the last long counts of this block, as "the bytes at x and x - d are equal for every
+    // x in [from, end), and not at end (or end is iHighLimit)", packed d | from << 16 | end << 32, in kRunSlots slots indexed
+    // by a hash of d.  Any other walk whose candidate lies d back and has matched up to somewhere inside [from, end] knows
+    // its count without reading a byte.  On input with a period every start point's first match is the SAME run (a 64 KiB
+    // block of period 256: 1 000 walks x 64 KiB; round 3, tools/cliff_probe.py: 4.4 GiB/s at level 9).
+    constexpr uint32_t kRunSlots = 8;                            // slot of a distance: the top bits of d x 2654435761 (periods are often powers of two)
+    [[maybe_unused]] lds_u64 *runs = nullptr;
     if constexpr (kLds) {
         lk = (const lds_u16 *)lds_raw;
-        bm_l = (lds_u32 *)(lds_raw + lk_bytes);
+        runs = (lds_u64 *)(lds_raw + lk_bytes);                  // kRunSlots counted runs, see below
+        bm_l = (lds_u32 *)(lds_raw + lk_bytes + kRunSlots * 8u);
         const uint32_t bm_words = (np + 31u) >> 5;
         next_seg = bm_l + bm_words;                              // [0] start-point counter, [1] frontier of the walk from 0, [2] that walk is over
         const u32x4 *g4 = reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(d_link_v) + (uint64_t)b * link_stride);
@@ -483,6 +544,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         const uint32_t n16 = (np * 2u + 15u) >> 4;
         for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) l4[k] = g4[k];
         for (uint32_t k = threadIdx.x; k <= bm_words + 2u; k += blockDim.x) bm_l[k] = 0;
+        if (threadIdx.x < kRunSlots) runs[threadIdx.x] = 0;
     } else {
         lk = static_cast<const uint32_t *>(d_link_v) + (uint64_t)b * link_stride;
         bm_g = d_bitmap + (uint64_t)b * bitmap_stride;
@@ -535,6 +597,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     int32_t nb = 0, best_len = (int32_t)kMinMatch - 1;
 #ifdef ZLZ4_STAMPS
     unsigned long long st_trips = 0, st_chain = 0, st_fetch = 0, st_walks = 0, t_assign = 0, t_fetch = 0, t_chain = 0;
+    unsigned long long st_counts = 0, st_known = 0, st_pats = 0, st_count_steps = 0, t_long = 0, st_miss_d = 0, st_miss_lo = 0, st_miss_hi = 0;
 #define HSTAMP(acc, t0) acc += __builtin_amdgcn_s_memtime() - t0
 #define HNOW() __builtin_amdgcn_s_memtime()
 #else
@@ -699,11 +762,44 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                     if (lane == L) { have = false; in_chain = false; in_ext = false; }
                     continue;
                 }
-                const uint32_t total = hc_coop_count(src, P, rdlane(m, L), rdlane(off, L), limit, n, lane);
+                const uint32_t M = rdlane(m, L), O = rdlane(off, L);
+                uint32_t total = 0;
+                [[maybe_unused]] const uint32_t d = P - M;
+                bool known = false;                              // a counted run answers it
+                [[maybe_unused]] uint32_t run_d = 0, run_from = 0, run_end = 0;
+                if constexpr (kLds) {
+                    const unsigned long long e = __hip_atomic_load(runs + ((d * 2654435761u) >> 29), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t e_lo = rfl((uint32_t)e);      // (one address: the same in every lane)
+                    run_d = e_lo & 0xFFFFu; run_from = e_lo >> 16; run_end = rfl((uint32_t)(e >> 32));
+                    known = run_d == d && run_from <= P + O && P + O <= run_end;
+                    total = run_end - P;
+                }
+#ifdef ZLZ4_STAMPS
+                st_known += known; st_counts += !known;
+                if (!known) { if (run_d != d) st_miss_d += 1; else if (P + O < run_from) st_miss_lo += 1; else st_miss_hi += 1; }
+#endif
+                if (!known) {
+                    total = hc_coop_count(src, P, M, O, limit, n, lane);
+#ifdef ZLZ4_STAMPS
+                    st_count_steps += (total - O) / 1024u + 1u;
+#endif
+                    if constexpr (kLds) {
+                        // (the same run counted from further down -- another wavefront's entry, this walk started below it:
+                        //  the entry keeps the lower start.  Not atomic with the load above: whatever lands is a true statement.)
+                        uint32_t nf = P + O;
+                        const uint32_t ne = P + total;
+                        if (run_d == d && run_end == ne && run_from < nf) nf = run_from;
+                        if (lane == L && total - O >= 1024u)       // (a count of one step is as cheap as the look-up: it only evicts)
+                            __hip_atomic_store(runs + ((d * 2654435761u) >> 29), (unsigned long long)d | ((unsigned long long)nf << 16) | ((unsigned long long)ne << 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
                 if (lane == L) { off = total; ext_final = true; }
             }
         }
+        HSTAMP(t_long, t0);
         // ---- one round trip of the chain walk :571-622
+        bool done = false;                                       // the search at pos is over
         if (have && in_chain && !parked) {
             // a candidate is done: :577, :586-:621.  `total` = its match length (bytes equal to the ones at pos, not yet
             // clamped), or 0 for a candidate that is known not to beat best_len (the reference counts those in full,
@@ -720,7 +816,6 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 m = stop ? c : c - delta;                        // :621
                 return (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0) & (int)(kLds || pos - m <= kMaxDist));   // :571, :573
             };
-            bool done = false;                                   // the search at pos is over
             if (!in_ext) {
                 // up to kCands candidates per trip: the links are chased first (the walk itself does not depend on the
                 // compares), then the 16-byte loads fly together.  A candidate can only matter if it matches MORE
@@ -754,7 +849,8 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 // beat best_len (or lies below lowestMatchIndex, :579), end[k] = the chain ends behind it (:620).
                 auto rejected = [&](uint32_t cc, uint32_t fdd) {
                     const uint32_t cl = fdd < avail ? fdd : avail;           // lz4Count stops at iHighLimit
-                    const bool r = w != 0u ? fdd != 16u : (fdd < kMinMatch) | ((fdd < 16u) & ((int32_t)cl <= best_len));
+                    bool r = w != 0u ? fdd != 16u : (fdd < kMinMatch) | ((fdd < 16u) & ((int32_t)cl <= best_len));
+                    r = r | ((int32_t)avail <= best_len);        // the best match ends at iHighLimit: lz4Count cannot return more (:234)
                     return kLds ? r : (r | (cc < lowest));
                 };
                 auto near_enough = [&](uint32_t cc) { return kLds || pos - cc <= kMaxDist; };
@@ -819,24 +915,62 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 if (more) off = total;
                 else { in_ext = false; done = !complete(m, delta, total); }
             }
-            if (done) {
-                if (pattern_analysis)
-                    hc_pattern_step<T, LinkPtr>(src, lk, pos, m, p16.x, lowest, limit, best_len, best_off);
-                const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
-#ifndef ZLZ4_EXPERIMENT_NOSTORE
-                if (found) res[pos] = pack(best_len, best_off);
+        }
+        // patternAnalysis (:626-676), whole wavefront per lane that gets there (rare outside runs of one byte; the
+        // three counts are each as long as the run)
+        if (pattern_analysis) {
+            const uint32_t pt = p16.x;
+            bool pat_here = done && best_len > 0 && ((pt & 0xFFFFu) == (pt >> 16)) && ((pt & 0xFFu) == (pt >> 24));   // :629-631
+            if (pat_here) pat_here = delta_of(m, lk[m]) == 1u;                                                       // :627
+            uint64_t patm = ballot(pat_here);
+            while (patm) {
+                const uint32_t L = first_lane(patm);
+                patm &= patm - 1ull;
+#ifdef ZLZ4_STAMPS
+                st_pats += 1;
 #endif
-                pos += found ? (uint32_t)best_len : 1u;          // :1013-1016, :382
-                in_chain = false;
+                const uint32_t P = rdlane(pos, L), M = rdlane(m, L), pattern = rdlane(pt, L);
+                const uint32_t low = kLds ? 0u : rdlane(lowest, L);
+                const uint32_t src_pat_len = hc_coop_count_pattern(src, P + 4u, limit, pattern, n, lane) + 4u;       // :633
+                const uint32_t cand = M - 1u;                                                                        // :636
+                if (cand >= low && rfl(ld32(src + cand)) == pattern) {                                               // :637, :644
+                    const uint32_t fwd_len = hc_coop_count_pattern(src, cand + 4u, limit, pattern, n, lane) + 4u;    // :646
+                    const uint32_t back_len = hc_coop_reverse_count_pattern(src, cand, pattern, lane);               // :650
+                    uint32_t lo = cand - back_len;                                                                   // :653
+                    if (lo < low) lo = low;
+                    const uint32_t lim_back = cand - lo;
+                    const uint32_t seg_total = lim_back + fwd_len;                                                   // :654
+                    const int32_t max_ml = (int32_t)(seg_total < src_pat_len ? seg_total : src_pat_len);             // :658
+                    const uint32_t new_m = (seg_total >= src_pat_len && fwd_len <= src_pat_len) ? cand + fwd_len - src_pat_len   // :660-662
+                                                                                                : cand - lim_back;   // :665
+                    if (lane == L && max_ml > best_len && (P - new_m) <= kMaxDist) {                                 // :669
+                        best_len = max_ml;
+                        best_off = P - new_m;
+                    }
+                }
             }
         }
+        if (done) {
+            const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
+#ifndef ZLZ4_EXPERIMENT_NOSTORE
+            if (found) res[pos] = pack(best_len, best_off);
+#endif
+            pos += found ? (uint32_t)best_len : 1u;          // :1013-1016, :382
+            in_chain = false;
+        }
         HSTAMP(t_chain, t0);
+        // a wavefront whose walks all wait for the frontier (or that only holds an offer open) leaves the issue slots to the others
+        if (!ballot((have && !parked) || (!have && !exhausted))) __builtin_amdgcn_s_sleep(8);
     }
 #ifdef ZLZ4_STAMPS
     if (lane == 0) {
         atomicAdd(&g_zlz4_hstamps[0], st_chain); atomicAdd(&g_zlz4_hstamps[1], st_trips); atomicAdd(&g_zlz4_hstamps[2], st_fetch);
         atomicAdd(&g_zlz4_hstamps[3], st_walks); atomicAdd(&g_zlz4_hstamps[4], t_assign); atomicAdd(&g_zlz4_hstamps[5], t_fetch);
         atomicAdd(&g_zlz4_hstamps[6], t_chain);
+        atomicAdd(&g_zlz4_hstamps[7], st_counts); atomicAdd(&g_zlz4_hstamps[8], st_known); atomicAdd(&g_zlz4_hstamps[9], st_pats);
+        atomicAdd(&g_zlz4_hstamps[10], st_count_steps); atomicAdd(&g_zlz4_hstamps[11], t_long);
+        atomicMax(&g_zlz4_hstamps[12], t_assign + t_fetch + t_chain);
+        atomicAdd(&g_zlz4_hstamps[13], st_miss_d); atomicAdd(&g_zlz4_hstamps[14], st_miss_lo); atomicAdd(&g_zlz4_hstamps[15], st_miss_hi);
     }
 #endif
 #undef HSTAMP
@@ -1042,7 +1176,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         if (threads > 1024u) threads = 1024u;
         if (threads < 64u) threads = 64u;
         const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
-        const uint32_t lds = kLds ? lk_bytes + ((np_max + 31u) / 32u + 3u) * 4u : 16u;
+        const uint32_t lds = kLds ? lk_bytes + 64u + ((np_max + 31u) / 32u + 3u) * 4u : 16u;   // links, counted runs, bitmap, 3 words
         static const int cands = [] { const char *e = zlz4_tune_env("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
         auto kern = cands == 8 ? &k_hc_seg_search<8, kLds> : cands == 4 ? &k_hc_seg_search<4, kLds> : cands == 2 ? &k_hc_seg_search<2, kLds> : &k_hc_seg_search<1, kLds>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
