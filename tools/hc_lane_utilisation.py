@@ -1,6 +1,6 @@
 """Diagnostic (-DZLZ4_STAMPS build): how many of the 64 lanes of the HC search kernel are still walking their chain
 per loop trip (k_hc_search: levels 10..12), and how its long counts go.
-Usage: ZLZ4_AMD_LIB=zig-lz4_amd/libzlz4_amd_stamps.so python tools/hc_lane_utilisation.py [level] [dist]"""
+Usage: ZLZ4_AMD_LIB=zig-lz4_amd/libzlz4_amd_stamps.so python tools/hc_lane_utilisation.py [level] [dist | periodN]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +8,11 @@ import torch, bench, zig_lz4_amd as zl
 dev = torch.device("cuda:0"); nblocks = 512; block = 65536
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dist = sys.argv[2] if len(sys.argv) > 2 else "text"
-inp = bench.make_device_blocks(dist, nblocks, block, dev, seed=1)
+if dist.startswith("period"):                      # periodN: random content repeated every N bytes
+    P = int(dist[6:]); g = torch.Generator(device=dev); g.manual_seed(5)
+    inp = torch.randint(0, 256, (nblocks, P), dtype=torch.uint8, device=dev, generator=g).repeat(1, block // P + 1)[:, :block].contiguous()
+else:
+    inp = bench.make_device_blocks(dist, nblocks, block, dev, seed=1)
 slot = (zl.compressBound(block) + 15) // 16 * 16
 ar = torch.arange(nblocks, dtype=torch.int64, device=dev)
 in_len = torch.full((nblocks,), block, dtype=torch.int32, device=dev)

@@ -517,6 +517,10 @@ __global__ __launch_bounds__(256) void k_hc_search(const uint8_t *__restrict__ d
                     best_len = mlt;
                     best_off = p - m;
                     if (mlt > max_attempts) break;               // :613
+                    // (the result is final at the limit, as above: in a block with a short period these last positions
+                    //  otherwise walk nbAttempts candidates that all match to the limit -- 16 384 dependent round trips
+                    //  of one lane at level 12, the straggler of every block)
+                    if ((uint32_t)mlt >= avail) { at_limit = true; break; }
                 }
             }
             const uint32_t delta = Links<T>::delta(m, lk);       // :619
@@ -828,11 +832,12 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                             best_len = mlt;
                             best_off = pos - m;
                             if (mlt > max_attempts) break;       // :613
+                            if ((uint32_t)mlt >= limit - pos) break;   // final: nothing is longer than up to iHighLimit, nor is the pattern step's maxML (:658)
                         }
                         if (delta == 0 || delta > m) break;      // :620
                         m -= delta;                              // :621
                     }
-                    if (pattern_analysis)
+                    if (pattern_analysis && (uint32_t)best_len < limit - pos)
                         hc_pattern_step<T, LinkPtr>(src, lk, pos, m, pattern, lowest, limit, best_len, best_off);
                     const bool found = best_len >= (int32_t)kMinMatch && best_off != 0;
                     if (found) res[pos] = pack(best_len, best_off);
