@@ -22,8 +22,12 @@
 //                         positions run speculatively, mark what they search, and stop where somebody else has been;
 //                         the walk from position 0 is the parse.  Only positions on some walk are searched (:571-622,
 //                         + the level-9 pattern analysis :626-678), four candidates per trip, matches stored per position.
+//                         Long counts are done by the wavefront and their outcome (a counted run) is shared by the
+//                         block's walks; the walk from 0 hands the parse over when it merges into another walk.
 //   K2  k_hc_search       (levels 10-12, whose price-based parse looks results up everywhere; and blocks > 64 KiB at
-//                         every level's A/B switch) one LANE per position walks its chain.
+//                         every level's A/B switch) one LANE per position walks its chain; a candidate is only counted
+//                         if its byte best_len matches, a search ends when its match reaches iHighLimit, counts beyond
+//                         64 bytes are done by the wavefront and shared by its lanes.
 //   K3  k_hc_parse_emit   one wavefront per block: the greedy walk of :1009-1032 over the stored results,
 //                         encodeSequence with its limitedOutput checks, final literals; runs on a side stream beside
 //                         K1 / K2s of the next round.
