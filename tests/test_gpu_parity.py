@@ -377,3 +377,21 @@ def test_compress_hc_periodic_inputs(zl, oracle, gpu, level):
     got = gh.compress_hc(zl, items, gpu, level)
     want = [oracle.compress_hc(b, level) for b in items]
     _cmp(["periodic%d" % i for i in range(len(items))], got, want)
+
+
+@pytest.mark.parametrize("level", [9, 12])
+def test_compress_hc_periodic_large_blocks(zl, oracle, gpu, level):
+    """The same kind of input in blocks > 64 KiB, i.e. through the search kernels' HBM-link variants (32-bit links, the
+    counted runs packed 16 + 24 + 24 bits): periods 1, 256, 5000, with and without damaged bytes, 150 .. 300 KB."""
+    rng = np.random.default_rng(777 + level)
+    items = []
+    for period, total in ((1, 300000), (256, 200000), (5000, 150000), (256, 262144 + 17)):
+        pat = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+        b = bytearray((pat * (total // period + 2))[:total])
+        items.append(bytes(b))
+        for _ in range(4):
+            b[int(rng.integers(0, len(b)))] ^= 0x3C
+        items.append(bytes(b))
+    got = gh.compress_hc(zl, items, gpu, level)
+    want = [oracle.compress_hc(b, level) for b in items]
+    _cmp(["periodic_large%d" % i for i in range(len(items))], got, want)

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
     lds_u32 *next_seg;                                           // start-point counter
     [[maybe_unused]] lds_u32 *bm_l = nullptr;                    // visited bitmap, one bit per position
     [[maybe_unused]] uint32_t *bm_g = nullptr;
-    // Counted runs (blocks <= 64 KiB): the last long counts of this block, as "the bytes at x and x - d are equal for every
+    // Counted runs (blocks <= 16 MiB): the last long counts of this block, as "the bytes at x and x - d are equal for every
     // x in [from, end), and not at end (or end is iHighLimit)", packed d | from << 16 | end << 32, in kRunSlots slots indexed
     // by a hash of d.  Any other walk whose candidate lies d back and has matched up to somewhere inside [from, end] knows
     // its count without reading a byte.  On input with a period every start point's first match is the SAME run (a 64 KiB
@@ -666,7 +666,12 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
         bm_g = d_bitmap + (uint64_t)b * bitmap_stride;
         next_seg = (lds_u32 *)lds_raw;
         if (threadIdx.x < 3u) next_seg[threadIdx.x] = 0;
+        runs = (lds_u64 *)(lds_raw + 16u);
+        if (threadIdx.x < kRunSlots) runs[threadIdx.x] = 0;
     }
+    // (an entry is d (16 bits) | from | end: 16 + 32 bits for a block <= 64 KiB, 24 + 24 for one <= 16 MiB; none beyond)
+    constexpr uint32_t kFromBits = kLds ? 16u : 24u;
+    const bool use_runs = kLds || n <= (1u << 24);
     __syncthreads();
     // what a link says: the first candidate of q (0 = none), the distance to the next one (:502-504, :619)
     auto first_of = [](uint32_t q, uint32_t raw) { return kLds ? q - raw : raw; };
@@ -896,10 +901,13 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
                 [[maybe_unused]] const uint32_t d = P - M;
                 bool known = false;                              // a counted run answers it
                 [[maybe_unused]] uint32_t run_d = 0, run_from = 0, run_end = 0;
-                if constexpr (kLds) {
+                if (use_runs) {
                     const unsigned long long e = __hip_atomic_load(runs + ((d * 2654435761u) >> 29), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const uint32_t e_lo = rfl((uint32_t)e);      // (one address: the same in every lane)
-                    run_d = e_lo & 0xFFFFu; run_from = e_lo >> 16; run_end = rfl((uint32_t)(e >> 32));
+                    const uint32_t e_lo = rfl((uint32_t)e), e_hi = rfl((uint32_t)(e >> 32));   // (one address: the same in every lane)
+                    const unsigned long long eu = ((unsigned long long)e_hi << 32) | e_lo;
+                    run_d = e_lo & 0xFFFFu;
+                    run_from = (uint32_t)(eu >> 16) & ((1u << kFromBits) - 1u);
+                    run_end = (uint32_t)(eu >> (16u + kFromBits));
                     known = run_d == d && run_from <= P + O && P + O <= run_end;
                     total = run_end - P;
                 }
@@ -912,14 +920,14 @@ __global__ __launch_bounds__(1024) void k_hc_seg_search(const uint8_t *__restric
 #ifdef ZLZ4_STAMPS
                     st_count_steps += (total - O) / 1024u + 1u;
 #endif
-                    if constexpr (kLds) {
+                    if (use_runs) {
                         // (the same run counted from further down -- another wavefront's entry, this walk started below it:
                         //  the entry keeps the lower start.  Not atomic with the load above: whatever lands is a true statement.)
                         uint32_t nf = P + O;
                         const uint32_t ne = P + total;
                         if (run_d == d && run_end == ne && run_from < nf) nf = run_from;
                         if (lane == L && total - O >= 1024u)       // (a count of one step is as cheap as the look-up: it only evicts)
-                            __hip_atomic_store(runs + ((d * 2654435761u) >> 29), (unsigned long long)d | ((unsigned long long)nf << 16) | ((unsigned long long)ne << 32),
+                            __hip_atomic_store(runs + ((d * 2654435761u) >> 29), (unsigned long long)d | ((unsigned long long)nf << 16) | ((unsigned long long)ne << (16u + kFromBits)),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
@@ -1305,7 +1313,7 @@ int launch_hc_chunked(hipStream_t stream, const uint8_t *d_in, const uint64_t *d
         if (threads > 1024u) threads = 1024u;
         if (threads < 64u) threads = 64u;
         const uint32_t lk_bytes = ((np_max * 2u + 15u) & ~15u) + 16u;        // + padding: the walk reads 3 links ahead
-        const uint32_t lds = kLds ? lk_bytes + 64u + ((np_max + 31u) / 32u + 3u) * 4u : 16u;   // links, counted runs, bitmap, 3 words
+        const uint32_t lds = kLds ? lk_bytes + 64u + ((np_max + 31u) / 32u + 3u) * 4u : 16u + 64u;   // links, counted runs, bitmap, 3 words | 3 words, counted runs
         static const int cands = [] { const char *e = zlz4_tune_env("ZLZ4_HC_CANDS"); return e ? atoi(e) : 4; }();
         auto kern = cands == 8 ? &k_hc_seg_search<8, kLds> : cands == 4 ? &k_hc_seg_search<4, kLds> : cands == 2 ? &k_hc_seg_search<2, kLds> : &k_hc_seg_search<1, kLds>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
